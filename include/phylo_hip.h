@@ -1,0 +1,154 @@
+/* phylo_hip.h -- C ABI of libphylo_hip.so: the MI355X-native Felsenstein-pruning likelihood and
+ * CSMC particle loop of amoretti86/phylo (vcsmc.py / csmc.py), behind plain pointers and sizes.
+ *
+ * The reference has no FFI of its own: the path sits behind Python methods.  Each
+ * entry point below names the reference method it stands in for (file:line into the reference);
+ * the Python classes in phylo_amd/ (VCSMC, CSMC) keep the reference's names and argument meaning and
+ * call these through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PHYLO_E* code on failure; the message is
+ *     available from phylo_last_error(ctx) (ctx may be NULL for failures of phylo_create);
+ *   - the caller owns every host buffer (C-contiguous; double = IEEE binary64, int32/int64 as named);
+ *     the library never keeps a host pointer past return;
+ *   - the library owns all device memory and releases it in phylo_destroy;
+ *   - a ctx is bound to ONE GPU and is not thread-safe; distinct ctxs are independent.  Multi-GPU =
+ *     one process (rank) per GPU, joined by phylo_comm_init (RCCL over xGMI);
+ *   - calls are synchronous at the boundary unless the name ends in _async;
+ *   - no global RNG state: every stochastic entry point takes (seed, step) and follows the
+ *     counter-based contract in DESIGN.md (Philox4x32-10).
+ *   - there is no CPU fallback: without a usable HIP device every compute entry point fails with
+ *     PHYLO_ENODEVICE.
+ */
+#ifndef PHYLO_HIP_H
+#define PHYLO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct phylo_ctx phylo_ctx;
+
+enum {
+    PHYLO_OK = 0,
+    PHYLO_EINVAL = -1,    /* bad argument (shape, NULL pointer, state not set) */
+    PHYLO_ENODEVICE = -2, /* no HIP device / device id out of range */
+    PHYLO_EHIP = -3,      /* a HIP runtime call failed */
+    PHYLO_ENOMEM = -4,    /* device allocation failed */
+    PHYLO_ECOMM = -5,     /* RCCL / multi-rank failure */
+    PHYLO_ESTATE = -6     /* call order (e.g. sweep before set_leaves/set_model) */
+};
+
+/* sweep / model flags */
+enum {
+    PHYLO_QUIRK_Q1_RAW_Q = 1u << 0,    /* weight subtracts q = 1/C(n,2) itself, not log q (vcsmc.py:298,392).
+                                          Set = as the reference.  */
+    PHYLO_TWISTING = 1u << 1,          /* twisted/nested proposal of vncsmc.py:295-416 (uses M)          */
+    PHYLO_TIME_KERNELS = 1u << 2,      /* bracket every merge launch with HIP events (profiling runs)    */
+    PHYLO_FLAGS_DEFAULT = PHYLO_QUIRK_Q1_RAW_Q
+};
+
+typedef struct phylo_stats {
+    double sweep_ms;        /* device time of the whole sweep (hipEvents on the ctx stream)            */
+    double merge_ms;        /* sum of merge-kernel launch durations (only with PHYLO_TIME_KERNELS)     */
+    int32_t merge_launches; /* number of merge launches in that sum                                    */
+    int32_t n_launches;     /* kernel launches in the sweep                                            */
+    double units;           /* particle-site-likelihoods computed by this rank: K_local * S * (N-1)    */
+    double alg_bytes;       /* 96 B * units (two child reads + one parent write, fp64 x 4 states)      */
+} phylo_stats;
+
+const char* phylo_version(void);
+const char* phylo_last_error(const phylo_ctx* ctx);
+
+/* Number of visible HIP devices (0 if none / no driver).  Does not create a context. */
+int phylo_device_count(void);
+
+/* VCSMC.__init__ + the sizes of sample_phylogenies (vcsmc.py:110-118, 406-426): K particles (global
+ * count), N taxa, S sites, A = 4 states.  device_ids/n_gpus: this build runs one GPU per process, so
+ * n_gpus must be 1; more GPUs join through phylo_comm_init. */
+int phylo_create(const int* device_ids, int n_gpus, int K, int N, int S, int A, uint32_t flags,
+                 phylo_ctx** out);
+int phylo_destroy(phylo_ctx* ctx);
+
+/* datadict['genome'] [N,S,4] float64 (runner.py:107-115); stored once, not K-replicated
+ * (the reference replicates it K-fold at vcsmc.py:479). */
+int phylo_set_leaves(phylo_ctx* ctx, const double* genome_NxSxA);
+
+/* Model of VCSMC.__init__ / get_Q / get_stationary_probs (vcsmc.py:119-148), already evaluated by the
+ * host: Q row-major 4x4, pi[4], lam_l / lam_r = exp(branch params) [N-1].  jc69_closed_form != 0 uses
+ * P_ii = 1/4 + 3/4 e^-t for the JC69 Q instead of the generic Pade expm. */
+int phylo_set_model(phylo_ctx* ctx, const double* Q16, const double* pi4, const double* lam_l,
+                    const double* lam_r, int jc69_closed_form);
+
+/* tf.linalg.expm(tensordot(t, Q, 0)) (vcsmc.py:181-184): P[i] = expm(Q * t[i]), [n,4,4]. */
+int phylo_expm_batched(phylo_ctx* ctx, const double* t, int n, double* P_nx4x4);
+
+/* VCSMC.broadcast_conditional_likelihood_K (vcsmc.py:180-188) == csmc.conditional_likelihood per
+ * particle (csmc.py:300-309): out[k,s,:] = (l[k,s,:] @ P(tl[k])) * (r[k,s,:] @ P(tr[k])). */
+int phylo_cond_likelihood_K(phylo_ctx* ctx, const double* l_KxSx4, const double* r_KxSx4,
+                            const double* tl_K, const double* tr_K, int K, int S, double* out_KxSx4);
+
+/* VCSMC.compute_forest_posterior (vcsmc.py:231-245): out[k] = sum_x sum_s log(pi . core[k,x,s,:])
+ *   - sum_x log (2 max(record[k,x], 2) - 3)!! */
+int phylo_forest_loglik(phylo_ctx* ctx, const double* core_KxXxSx4, const int32_t* record_KxX, int K,
+                        int X, int S, double* out_K);
+
+/* CSMC.compute_log_conditional_likelihood (csmc.py:318-326) on an explicit binary tree.  Nodes
+ * 0..n_leaves-1 are leaves (rows of leaves_LxSx4); node i >= n_leaves has children left[i], right[i]
+ * (already-numbered nodes < i or leaves) with branch lengths bl[i], br[i].  prior4 is csmc's
+ * `self.prior`.  out_loglik = sum_s log(prior . data_root[s]); root_data_Sx4 may be NULL. */
+int phylo_tree_loglik(phylo_ctx* ctx, int n_nodes, int n_leaves, int S, const int32_t* left,
+                      const int32_t* right, const double* bl, const double* br, int root,
+                      const double* leaves_LxSx4, const double* prior4, double* out_loglik,
+                      double* root_data_Sx4);
+
+/* VCSMC.resample's index draw (vcsmc.py:284-285) / CSMC.resample (csmc.py:218-228): K iid draws from
+ * softmax(logw), by the integer-CDF contract.  idx_K[k] in [0,K). */
+int phylo_resample(phylo_ctx* ctx, const double* logw_K, int K, uint64_t seed, uint32_t step,
+                   int64_t* idx_K);
+
+/* VCSMC.compute_log_ZSMC (vcsmc.py:270-277): sum_r logsumexp_k(logw[r,k] - log K). */
+int phylo_log_zsmc(phylo_ctx* ctx, const double* logw_RxK, int R, int K, double* out);
+
+/* VCSMC.sample_phylogenies (vcsmc.py:406-451): the N-1 rank events, device-resident.  Any output
+ * pointer may be NULL.  Shapes (K = this rank's particles when sharded, see phylo_comm_init):
+ *   log_weights, log_lik, lbranch, rbranch : [(N-1), K]   (rows 1..N-1 of the reference's tensors)
+ *   merges    : [(N-1), K, 2]  root-table slots (left, right) coalesced at each rank event
+ *   ancestors : [(N-2), K]     resampling indices drawn before rank events 1..N-2 (global indices)
+ *   logZ      : scalar; perf : timing of this sweep
+ * M is the number of sub-samples of the twisted proposal (ignored without PHYLO_TWISTING). */
+int phylo_sweep(phylo_ctx* ctx, uint64_t seed, uint32_t flags, int M, double* log_weights,
+                double* log_lik, double* lbranch, double* rbranch, int32_t* merges, int64_t* ancestors,
+                double* logZ, phylo_stats* perf);
+
+/* Same sweep, left on the device (no host copies); phylo_sweep_fetch copies the last sweep's outputs. */
+int phylo_sweep_async(phylo_ctx* ctx, uint64_t seed, uint32_t flags, int M);
+int phylo_sweep_fetch(phylo_ctx* ctx, double* log_weights, double* log_lik, double* lbranch,
+                      double* rbranch, int32_t* merges, int64_t* ancestors, double* logZ,
+                      phylo_stats* perf);
+int phylo_synchronize(phylo_ctx* ctx);
+
+/* Partial-likelihood vector of the node created at rank event r by particle slot k in the last sweep,
+ * [S,4] (test surface for the merge kernel inside the sweep). */
+int phylo_sweep_node(phylo_ctx* ctx, int r, int k, double* out_Sx4);
+
+/* Bit-level probe of the device arithmetic contract: op 0 exp(x), 1 log(x), 2 x/y, 3 fma(x,y,x). */
+int phylo_math_probe(phylo_ctx* ctx, int op, const double* x, const double* y, int n, double* out);
+
+/* ---- multi-GPU: one process per GPU, particles sharded by contiguous ranges ------------------- */
+#define PHYLO_COMM_ID_BYTES 128
+/* rank 0 makes the id (ncclGetUniqueId) and hands it to the other ranks out of band. */
+int phylo_comm_unique_id(char id[PHYLO_COMM_ID_BYTES]);
+/* Join `world` ranks.  The ctx must have been created with the GLOBAL K; afterwards this rank owns
+ * particles [rank*K/world, (rank+1)*K/world) and sweep outputs are this shard's columns. */
+int phylo_comm_init(phylo_ctx* ctx, int rank, int world, const char id[PHYLO_COMM_ID_BYTES]);
+/* barrier + max over ranks of *value (RCCL all-reduce); identity when no comm is set. */
+int phylo_comm_max(phylo_ctx* ctx, double* value);
+int phylo_comm_barrier(phylo_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHYLO_HIP_H */

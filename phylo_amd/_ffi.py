@@ -1,0 +1,234 @@
+"""ctypes binding of libphylo_hip.so (include/phylo_hip.h).  No PyTorch, no CPU fallback.
+
+The shared object is built in-tree by phylo_amd/csrc/build.sh (hipcc --offload-arch=gfx950).  Loading
+fails loudly if it is missing; every compute call fails loudly (PhyloError) if no HIP device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libphylo_hip.so")
+
+PHYLO_OK = 0
+QUIRK_Q1_RAW_Q = 1 << 0
+TWISTING = 1 << 1
+TIME_KERNELS = 1 << 2
+FLAGS_DEFAULT = QUIRK_Q1_RAW_Q
+COMM_ID_BYTES = 128
+
+EXPORTS = [
+    "phylo_version", "phylo_last_error", "phylo_device_count", "phylo_create", "phylo_destroy",
+    "phylo_set_leaves", "phylo_set_model", "phylo_expm_batched", "phylo_cond_likelihood_K",
+    "phylo_forest_loglik", "phylo_tree_loglik", "phylo_resample", "phylo_log_zsmc", "phylo_sweep",
+    "phylo_sweep_async", "phylo_sweep_fetch", "phylo_synchronize", "phylo_sweep_node", "phylo_math_probe",
+    "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_max", "phylo_comm_barrier",
+]
+
+
+class PhyloError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libphylo_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [("sweep_ms", C.c_double), ("merge_ms", C.c_double), ("merge_launches", C.c_int32),
+                ("n_launches", C.c_int32), ("units", C.c_double), ("alg_bytes", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load the library once; raises OSError with a build hint if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("%s not found: build it with phylo_amd/csrc/build.sh (needs hipcc); "
+                          "there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.phylo_version.restype = C.c_char_p
+        lib.phylo_last_error.restype = C.c_char_p
+        lib.phylo_last_error.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    return int(load().phylo_device_count())
+
+
+class Context:
+    """Owns one phylo_ctx (one GPU).  Mirrors the C ABI one to one; numpy arrays in, numpy arrays out."""
+
+    def __init__(self, K, N, S, A=4, device=0, flags=FLAGS_DEFAULT):
+        self._lib = load()
+        self._h = C.c_void_p()
+        self.K, self.N, self.S, self.A = int(K), int(N), int(S), int(A)
+        self.K_local, self.k0 = self.K, 0
+        dev = (C.c_int * 1)(int(device))
+        rc = self._lib.phylo_create(dev, C.c_int(1), C.c_int(self.K), C.c_int(self.N), C.c_int(self.S), C.c_int(self.A),
+                                    C.c_uint32(flags), C.byref(self._h))
+        if rc != PHYLO_OK:
+            raise PhyloError(rc, (self._lib.phylo_last_error(None) or b"").decode())
+
+    def _check(self, rc):
+        if rc != PHYLO_OK:
+            raise PhyloError(rc, (self._lib.phylo_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.phylo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- state
+    def set_leaves(self, genome_NxSxA):
+        g = _f64(genome_NxSxA)
+        if g.shape != (self.N, self.S, self.A):
+            raise ValueError("genome shape %r != (%d, %d, %d)" % (g.shape, self.N, self.S, self.A))
+        self._check(self._lib.phylo_set_leaves(self._h, _ptr(g)))
+
+    def set_model(self, Q, pi, lam_l, lam_r, jc69_closed_form=False):
+        Q, pi, ll, lr = _f64(Q), _f64(pi).reshape(-1), _f64(lam_l), _f64(lam_r)
+        if Q.shape != (4, 4) or pi.shape != (4,) or ll.shape != (self.N - 1,) or lr.shape != (self.N - 1,):
+            raise ValueError("bad model shapes")
+        self._check(self._lib.phylo_set_model(self._h, _ptr(Q), _ptr(pi), _ptr(ll), _ptr(lr), C.c_int(int(jc69_closed_form))))
+
+    # ---- ops
+    def expm_batched(self, t):
+        t = _f64(np.atleast_1d(t))
+        P = np.empty((t.size, 4, 4))
+        self._check(self._lib.phylo_expm_batched(self._h, _ptr(t), C.c_int(t.size), _ptr(P)))
+        return P
+
+    def cond_likelihood_K(self, l, r, tl, tr):
+        l, r, tl, tr = _f64(l), _f64(r), _f64(tl), _f64(tr)
+        if l.ndim != 3 or l.shape != r.shape or l.shape[2] != 4 or tl.shape != (l.shape[0],) or tr.shape != tl.shape:
+            raise ValueError("bad shapes for cond_likelihood_K")
+        out = np.empty_like(l)
+        self._check(self._lib.phylo_cond_likelihood_K(self._h, _ptr(l), _ptr(r), _ptr(tl), _ptr(tr), C.c_int(l.shape[0]),
+                                                      C.c_int(l.shape[1]), _ptr(out)))
+        return out
+
+    def forest_loglik(self, core_KxXxSx4, record_KxX):
+        core = _f64(core_KxXxSx4)
+        rec = np.ascontiguousarray(record_KxX, dtype=np.int32)
+        if core.ndim != 4 or core.shape[3] != 4 or rec.shape != core.shape[:2]:
+            raise ValueError("bad shapes for forest_loglik")
+        K, X, S = core.shape[:3]
+        out = np.empty(K)
+        self._check(self._lib.phylo_forest_loglik(self._h, _ptr(core), _ptr(rec), C.c_int(K), C.c_int(X), C.c_int(S), _ptr(out)))
+        return out
+
+    def tree_loglik(self, left, right, bl, br, root, leaves, prior, want_root=True):
+        leaves, prior = _f64(leaves), _f64(prior).reshape(-1)
+        left = np.ascontiguousarray(left, dtype=np.int32)
+        right = np.ascontiguousarray(right, dtype=np.int32)
+        bl, br = _f64(bl), _f64(br)
+        n_nodes, L, S = left.shape[0], leaves.shape[0], leaves.shape[1]
+        out = C.c_double()
+        rd = np.empty((S, 4)) if want_root else None
+        self._check(self._lib.phylo_tree_loglik(self._h, C.c_int(n_nodes), C.c_int(L), C.c_int(S), _ptr(left), _ptr(right),
+                                                _ptr(bl), _ptr(br), C.c_int(int(root)), _ptr(leaves), _ptr(prior),
+                                                C.byref(out), _ptr(rd)))
+        return out.value, rd
+
+    def resample(self, logw, seed, step):
+        w = _f64(logw).reshape(-1)
+        idx = np.empty(w.size, dtype=np.int64)
+        self._check(self._lib.phylo_resample(self._h, _ptr(w), C.c_int(w.size), C.c_uint64(seed), C.c_uint32(step), _ptr(idx)))
+        return idx
+
+    def log_zsmc(self, logw_RxK):
+        w = _f64(logw_RxK)
+        out = C.c_double()
+        self._check(self._lib.phylo_log_zsmc(self._h, _ptr(w), C.c_int(w.shape[0]), C.c_int(w.shape[1]), C.byref(out)))
+        return out.value
+
+    def math_probe(self, op, x, y=None):
+        x = _f64(x).reshape(-1)
+        y = _f64(x if y is None else y).reshape(-1)
+        out = np.empty_like(x)
+        self._check(self._lib.phylo_math_probe(self._h, C.c_int(op), _ptr(x), _ptr(y), C.c_int(x.size), _ptr(out)))
+        return out
+
+    # ---- sweep
+    def sweep_async(self, seed, flags=FLAGS_DEFAULT, M=1):
+        self._check(self._lib.phylo_sweep_async(self._h, C.c_uint64(seed), C.c_uint32(flags), C.c_int(M)))
+
+    def synchronize(self):
+        self._check(self._lib.phylo_synchronize(self._h))
+
+    def sweep_fetch(self, arrays=True):
+        R, K = self.N - 1, self.K_local
+        out = {}
+        if arrays:
+            out = {'log_weights': np.empty((R, K)), 'log_likelihood': np.empty((R, K)),
+                   'left_branches': np.empty((R, K)), 'right_branches': np.empty((R, K)),
+                   'merges': np.empty((R, K, 2), dtype=np.int32),
+                   'ancestors': np.empty((max(R - 1, 0), K), dtype=np.int64)}
+        z = C.c_double()
+        st = Stats()
+        g = out.get
+        self._check(self._lib.phylo_sweep_fetch(self._h, _ptr(g('log_weights')), _ptr(g('log_likelihood')),
+                                                _ptr(g('left_branches')), _ptr(g('right_branches')), _ptr(g('merges')),
+                                                _ptr(g('ancestors')), C.byref(z), C.byref(st)))
+        out['logZ'] = z.value
+        out['stats'] = {f: getattr(st, f) for f, _ in Stats._fields_}
+        return out
+
+    def sweep(self, seed, flags=FLAGS_DEFAULT, M=1):
+        self.sweep_async(seed, flags, M)
+        return self.sweep_fetch()
+
+    def sweep_node(self, r, k):
+        out = np.empty((self.S, 4))
+        self._check(self._lib.phylo_sweep_node(self._h, C.c_int(r), C.c_int(k), _ptr(out)))
+        return out
+
+    # ---- multi-GPU
+    def comm_init(self, rank, world, comm_id):
+        buf = C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
+        self._check(self._lib.phylo_comm_init(self._h, C.c_int(rank), C.c_int(world), buf))
+        self.K_local = self.K // world
+        self.k0 = rank * self.K_local
+
+    def comm_max(self, value):
+        v = C.c_double(float(value))
+        self._check(self._lib.phylo_comm_max(self._h, C.byref(v)))
+        return v.value
+
+    def comm_barrier(self):
+        self._check(self._lib.phylo_comm_barrier(self._h))
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().phylo_comm_unique_id(buf)
+    if rc != PHYLO_OK:
+        raise PhyloError(rc, (load().phylo_last_error(None) or b"").decode())
+    return buf.raw

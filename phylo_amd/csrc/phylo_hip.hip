@@ -1,0 +1,653 @@
+// phylo_hip.hip -- C ABI (include/phylo_hip.h) over the gfx950 kernels in phylo_kernels.h.
+// One context = one GPU, one stream.  No CPU fallback: without a HIP device every entry point fails.
+#include "../../include/phylo_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "phylo_comm.h"
+#include "phylo_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct phylo_ctx {
+    int device = 0;
+    int K = 0, N = 0, S = 0, A = 4;      // K = global particle count
+    int Kloc = 0, k0 = 0;                // this rank's shard
+    int rank = 0, world = 1;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> kev;         // per-merge-launch events (PHYLO_TIME_KERNELS)
+    std::string err;
+    bool have_leaves = false, have_model = false, swept = false;
+    int jc = 0;
+    std::vector<double> h_lam_l, h_lam_r, h_ldf;
+    // model + leaves
+    double *d_Q = nullptr, *d_pi = nullptr, *d_lam_l = nullptr, *d_lam_r = nullptr, *d_ldf = nullptr;
+    double* d_leaves = nullptr;          // [N][S][4]
+    // sweep state
+    double* d_pool = nullptr;            // [(N-1)][Kloc][S][4]
+    double* d_nodell = nullptr;          // [N + (N-1)*K]
+    double *d_bl = nullptr, *d_br = nullptr, *d_Pmat = nullptr;   // [(N-1)][Kloc](x32)
+    double *d_logw = nullptr, *d_ll = nullptr;                    // [(N-1)][K] (global columns)
+    double* d_aux = nullptr;             // [Kloc][PK_AUX]
+    double* d_lse = nullptr;             // [N-1] + total
+    int32_t *d_roots[2] = {nullptr, nullptr}, *d_cnt[2] = {nullptr, nullptr};   // [K][N]
+    int32_t* d_child = nullptr;          // [Kloc][2]
+    int32_t* d_merges = nullptr;         // [(N-1)][Kloc][2]
+    int64_t* d_anc = nullptr;            // [(N-2)][Kloc]
+    uint64_t* d_cdf = nullptr;           // [K]
+    phylo_stats stats{};
+    uint32_t last_flags = 0;
+    int n_merge_events = 0;
+    // grow-only scratch for the op-level entry points
+    DevBuf scratch[6];
+    phylo_comm comm;
+};
+
+namespace {
+
+int fail(phylo_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? PHYLO_ENOMEM : PHYLO_EHIP, "%s failed: %s (%s:%d)", \
+                        #call, hipGetErrorString(e_), __FILE__, __LINE__);                            \
+    } while (0)
+
+#define CHK(expr)                   \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != PHYLO_OK) return rc_; \
+    } while (0)
+
+template <typename T>
+int dalloc(phylo_ctx* ctx, T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIPCHK(ctx, hipMalloc((void**)p, count * sizeof(T)));
+    return PHYLO_OK;
+}
+
+int scratch_get(phylo_ctx* ctx, int slot, size_t bytes, void** out) {
+    DevBuf& b = ctx->scratch[slot];
+    if (b.bytes < bytes) {
+        if (b.p) HIPCHK(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+        HIPCHK(ctx, hipMalloc(&b.p, bytes ? bytes : 16));
+        b.bytes = bytes;
+    }
+    *out = b.p;
+    return PHYLO_OK;
+}
+
+int bind(phylo_ctx* ctx) {
+    if (!ctx) return fail(nullptr, PHYLO_EINVAL, "ctx is NULL");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return PHYLO_OK;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// -log (2 max(c,2) - 3)!! by the reference's loop (vcsmc.py:30-57): n, n-2, ... while >= 2
+double host_log_double_factorial(int m) {
+    double res = 0.0;
+    for (int v = m; v >= 2; v -= 2) res = res + pm_log((double)v);
+    return res;
+}
+
+int launch_check(phylo_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(ctx, PHYLO_EHIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return PHYLO_OK;
+}
+
+void free_sweep_state(phylo_ctx* c) {
+    void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
+                    c->d_roots[0], c->d_roots[1], c->d_cnt[0], c->d_cnt[1], c->d_child, c->d_merges, c->d_anc,
+                    c->d_cdf};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c->d_pool = c->d_nodell = c->d_bl = c->d_br = c->d_Pmat = c->d_logw = c->d_ll = c->d_aux = c->d_lse = nullptr;
+    c->d_roots[0] = c->d_roots[1] = c->d_cnt[0] = c->d_cnt[1] = c->d_child = c->d_merges = nullptr;
+    c->d_anc = nullptr;
+    c->d_cdf = nullptr;
+}
+
+int alloc_sweep_state(phylo_ctx* c) {
+    free_sweep_state(c);
+    const size_t R = (size_t)c->N - 1, K = c->K, Kl = c->Kloc, N = c->N, S = c->S;
+    CHK(dalloc(c, &c->d_pool, R * Kl * S * 4));
+    CHK(dalloc(c, &c->d_nodell, N + R * K));
+    CHK(dalloc(c, &c->d_bl, R * Kl));
+    CHK(dalloc(c, &c->d_br, R * Kl));
+    CHK(dalloc(c, &c->d_Pmat, R * Kl * 32));
+    CHK(dalloc(c, &c->d_logw, R * K));
+    CHK(dalloc(c, &c->d_ll, R * K));
+    CHK(dalloc(c, &c->d_aux, Kl * PK_AUX));
+    CHK(dalloc(c, &c->d_lse, R + 1));
+    for (int i = 0; i < 2; ++i) {
+        CHK(dalloc(c, &c->d_roots[i], K * N));
+        CHK(dalloc(c, &c->d_cnt[i], K * N));
+    }
+    CHK(dalloc(c, &c->d_child, Kl * 2));
+    CHK(dalloc(c, &c->d_merges, R * Kl * 2));
+    CHK(dalloc(c, &c->d_anc, (R > 0 ? R - 1 : 0) * Kl));
+    CHK(dalloc(c, &c->d_cdf, K));
+    return PHYLO_OK;
+}
+
+// leaf node log-likelihoods sum_s log(pi . leaf[s]) (depend on pi and the leaves)
+int refresh_leaf_ll(phylo_ctx* c) {
+    if (!(c->have_leaves && c->have_model)) return PHYLO_OK;
+    hipLaunchKernelGGL(pk_row_loglik, dim3(c->N), dim3(PK_COLS), 0, c->stream, c->d_leaves, c->d_pi, c->S,
+                       c->d_nodell);
+    return launch_check(c, "pk_row_loglik(leaves)");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* phylo_version(void) { return "phylo_hip 0.1 (gfx950)"; }
+
+const char* phylo_last_error(const phylo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int phylo_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int phylo_create(const int* device_ids, int n_gpus, int K, int N, int S, int A, uint32_t flags,
+                 phylo_ctx** out) {
+    if (!out) return fail(nullptr, PHYLO_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (n_gpus != 1)
+        return fail(nullptr, PHYLO_EINVAL, "n_gpus must be 1 (one process per GPU; join ranks with phylo_comm_init)");
+    if (A != 4) return fail(nullptr, PHYLO_EINVAL, "A must be 4 (DNA alphabet), got %d", A);
+    if (K < 1 || N < 2 || S < 1) return fail(nullptr, PHYLO_EINVAL, "need K >= 1, N >= 2, S >= 1 (K=%d N=%d S=%d)", K, N, S);
+    if (N > PK_MAX_TAXA) return fail(nullptr, PHYLO_EINVAL, "N = %d exceeds the supported maximum %d", N, PK_MAX_TAXA);
+    if ((double)(N - 1) * K + N > 2.0e9) return fail(nullptr, PHYLO_EINVAL, "node ids overflow int32");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, PHYLO_ENODEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    const int dev = device_ids ? device_ids[0] : 0;
+    if (dev < 0 || dev >= ndev) return fail(nullptr, PHYLO_ENODEVICE, "device id %d out of range [0,%d)", dev, ndev);
+    phylo_ctx* c = new phylo_ctx();
+    c->device = dev;
+    c->K = K; c->N = N; c->S = S; c->A = A;
+    c->Kloc = K; c->k0 = 0;
+    c->flags = flags;
+    int rc = PHYLO_OK;
+    do {
+        if ((rc = bind(c)) != PHYLO_OK) break;
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(c, PHYLO_EHIP, "hipStreamCreate failed"); break; }
+        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = fail(c, PHYLO_EHIP, "hipEventCreate failed"); break; }
+        if ((rc = dalloc(c, &c->d_Q, 16)) != PHYLO_OK) break;
+        if ((rc = dalloc(c, &c->d_pi, 4)) != PHYLO_OK) break;
+        if ((rc = dalloc(c, &c->d_lam_l, (size_t)N)) != PHYLO_OK) break;
+        if ((rc = dalloc(c, &c->d_lam_r, (size_t)N)) != PHYLO_OK) break;
+        if ((rc = dalloc(c, &c->d_ldf, (size_t)N + 1)) != PHYLO_OK) break;
+        if ((rc = dalloc(c, &c->d_leaves, (size_t)N * S * 4)) != PHYLO_OK) break;
+        if ((rc = alloc_sweep_state(c)) != PHYLO_OK) break;
+        // table of log (2 max(c,2) - 3)!! by leaf count c = 0..N
+        c->h_ldf.resize((size_t)N + 1);
+        for (int cnt = 0; cnt <= N; ++cnt) c->h_ldf[cnt] = host_log_double_factorial(2 * (cnt > 2 ? cnt : 2) - 3);
+        if (hipMemcpy(c->d_ldf, c->h_ldf.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, PHYLO_EHIP, "ldf upload failed"); break; }
+    } while (0);
+    if (rc != PHYLO_OK) {
+        g_last_error = c->err;
+        phylo_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return PHYLO_OK;
+}
+
+int phylo_destroy(phylo_ctx* c) {
+    if (!c) return PHYLO_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    phylo_comm_destroy(&c->comm);
+    free_sweep_state(c);
+    void* ptrs[] = {c->d_Q, c->d_pi, c->d_lam_l, c->d_lam_r, c->d_ldf, c->d_leaves};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& b : c->scratch)
+        if (b.p) (void)hipFree(b.p);
+    for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PHYLO_OK;
+}
+
+int phylo_set_leaves(phylo_ctx* c, const double* genome) {
+    CHK(bind(c));
+    if (!genome) return fail(c, PHYLO_EINVAL, "genome_NxSxA is NULL");
+    HIPCHK(c, hipMemcpyAsync(c->d_leaves, genome, (size_t)c->N * c->S * 4 * 8, hipMemcpyHostToDevice, c->stream));
+    c->have_leaves = true;
+    CHK(refresh_leaf_ll(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_set_model(phylo_ctx* c, const double* Q16, const double* pi4, const double* lam_l, const double* lam_r,
+                    int jc69_closed_form) {
+    CHK(bind(c));
+    if (!Q16 || !pi4 || !lam_l || !lam_r) return fail(c, PHYLO_EINVAL, "NULL model pointer");
+    const int R = c->N - 1;
+    for (int i = 0; i < R; ++i)
+        if (!(lam_l[i] > 0.0) || !(lam_r[i] > 0.0)) return fail(c, PHYLO_EINVAL, "branch rates must be positive");
+    c->h_lam_l.assign(lam_l, lam_l + R);
+    c->h_lam_r.assign(lam_r, lam_r + R);
+    c->jc = jc69_closed_form ? 1 : 0;
+    HIPCHK(c, hipMemcpyAsync(c->d_Q, Q16, 16 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_pi, pi4, 4 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_lam_l, lam_l, (size_t)R * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_lam_r, lam_r, (size_t)R * 8, hipMemcpyHostToDevice, c->stream));
+    c->have_model = true;
+    CHK(refresh_leaf_ll(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_expm_batched(phylo_ctx* c, const double* t, int n, double* P) {
+    CHK(bind(c));
+    if (!c->have_model) return fail(c, PHYLO_ESTATE, "phylo_set_model has not been called");
+    if (n < 0 || (n > 0 && (!t || !P))) return fail(c, PHYLO_EINVAL, "bad arguments to phylo_expm_batched");
+    if (n == 0) return PHYLO_OK;
+    void *dt, *dP;
+    CHK(scratch_get(c, 0, (size_t)n * 8, &dt));
+    CHK(scratch_get(c, 1, (size_t)n * 16 * 8, &dP));
+    HIPCHK(c, hipMemcpyAsync(dt, t, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pk_expm_batched, dim3(cdiv(n, 64)), dim3(64), 0, c->stream, c->d_Q, (const double*)dt, n, c->jc,
+                       (double*)dP);
+    CHK(launch_check(c, "pk_expm_batched"));
+    HIPCHK(c, hipMemcpyAsync(P, dP, (size_t)n * 16 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_cond_likelihood_K(phylo_ctx* c, const double* l, const double* r, const double* tl, const double* tr, int K,
+                            int S, double* out) {
+    CHK(bind(c));
+    if (!c->have_model) return fail(c, PHYLO_ESTATE, "phylo_set_model has not been called");
+    if (K < 0 || S < 0) return fail(c, PHYLO_EINVAL, "negative shape");
+    if (K == 0 || S == 0) return PHYLO_OK;
+    if (!l || !r || !tl || !tr || !out) return fail(c, PHYLO_EINVAL, "NULL pointer");
+    const size_t nb = (size_t)K * S * 4 * 8;
+    void *dl, *dr, *dt, *dP, *dout;
+    CHK(scratch_get(c, 0, nb, &dl));
+    CHK(scratch_get(c, 1, nb, &dr));
+    CHK(scratch_get(c, 2, (size_t)2 * K * 8, &dt));
+    CHK(scratch_get(c, 3, (size_t)2 * K * 16 * 8, &dP));
+    CHK(scratch_get(c, 4, nb, &dout));
+    HIPCHK(c, hipMemcpyAsync(dl, l, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dr, r, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dt, tl, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((double*)dt + K, tr, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pk_expm_batched, dim3(cdiv(2 * K, 64)), dim3(64), 0, c->stream, c->d_Q, (const double*)dt, 2 * K,
+                       c->jc, (double*)dP);
+    CHK(launch_check(c, "pk_expm_batched"));
+    hipLaunchKernelGGL(pk_merge_api, dim3(K), dim3(PK_COLS), 0, c->stream, (const double*)dl, (const double*)dr,
+                       (const double*)dP, K, S, (double*)dout);
+    CHK(launch_check(c, "pk_merge_api"));
+    HIPCHK(c, hipMemcpyAsync(out, dout, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_forest_loglik(phylo_ctx* c, const double* core, const int32_t* record, int K, int X, int S, double* out) {
+    CHK(bind(c));
+    if (!c->have_model) return fail(c, PHYLO_ESTATE, "phylo_set_model has not been called");
+    if (K < 0 || X < 0 || S < 0) return fail(c, PHYLO_EINVAL, "negative shape");
+    if (K == 0) return PHYLO_OK;
+    if (!out || (X > 0 && (!core || !record))) return fail(c, PHYLO_EINVAL, "NULL pointer");
+    const size_t rows = (size_t)K * X;
+    void *dcore, *drec, *drow, *dout;
+    CHK(scratch_get(c, 0, rows * S * 4 * 8, &dcore));
+    CHK(scratch_get(c, 1, rows * 4, &drec));
+    CHK(scratch_get(c, 2, rows * 8, &drow));
+    CHK(scratch_get(c, 3, (size_t)K * 8, &dout));
+    if (rows) {
+        HIPCHK(c, hipMemcpyAsync(dcore, core, rows * S * 4 * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(drec, record, rows * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(pk_row_loglik, dim3((unsigned)rows), dim3(PK_COLS), 0, c->stream, (const double*)dcore, c->d_pi, S,
+                           (double*)drow);
+        CHK(launch_check(c, "pk_row_loglik"));
+    }
+    hipLaunchKernelGGL(pk_forest_tail, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, (const double*)drow,
+                       (const int32_t*)drec, c->d_ldf, c->N, K, X, (double*)dout);
+    CHK(launch_check(c, "pk_forest_tail"));
+    HIPCHK(c, hipMemcpyAsync(out, dout, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_tree_loglik(phylo_ctx* c, int n_nodes, int n_leaves, int S, const int32_t* left, const int32_t* right,
+                      const double* bl, const double* br, int root, const double* leaves, const double* prior4,
+                      double* out_loglik, double* root_data) {
+    CHK(bind(c));
+    if (!c->have_model) return fail(c, PHYLO_ESTATE, "phylo_set_model has not been called (Q is needed)");
+    if (n_leaves < 1 || n_nodes < n_leaves || S < 1 || root < 0 || root >= n_nodes)
+        return fail(c, PHYLO_EINVAL, "bad tree sizes (n_nodes=%d n_leaves=%d S=%d root=%d)", n_nodes, n_leaves, S, root);
+    if (!leaves || !prior4 || !out_loglik || (n_nodes > n_leaves && (!left || !right || !bl || !br)))
+        return fail(c, PHYLO_EINVAL, "NULL pointer");
+    // children-before-parents order of the internal nodes reachable from root (csmc.py:259-298)
+    std::vector<int32_t> order;
+    std::vector<double> ts;
+    {
+        std::vector<char> state((size_t)n_nodes, 0);
+        std::vector<int> stack{root};
+        while (!stack.empty()) {
+            const int v = stack.back();
+            if (v < n_leaves) { stack.pop_back(); continue; }
+            const int lc = left[v], rc = right[v];
+            if (lc < 0 || lc >= n_nodes || rc < 0 || rc >= n_nodes || lc == v || rc == v)
+                return fail(c, PHYLO_EINVAL, "node %d has invalid children (%d, %d)", v, lc, rc);
+            if (state[v] == 0) {
+                state[v] = 1;
+                stack.push_back(lc);
+                stack.push_back(rc);
+            } else {
+                stack.pop_back();
+                if (state[v] == 1) {
+                    state[v] = 2;
+                    order.push_back(v); order.push_back(lc); order.push_back(rc);
+                    ts.push_back(bl[v]); ts.push_back(br[v]);
+                }
+            }
+            if ((int)stack.size() > 4 * n_nodes + 8) return fail(c, PHYLO_EINVAL, "tree contains a cycle");
+        }
+    }
+    const int n_int = (int)(order.size() / 3);
+    void *dnodes, *dorder, *dt, *dP, *dpr, *dout;
+    CHK(scratch_get(c, 0, (size_t)n_nodes * S * 4 * 8, &dnodes));
+    CHK(scratch_get(c, 1, (size_t)(n_int ? n_int : 1) * 3 * 4, &dorder));
+    CHK(scratch_get(c, 2, (size_t)(n_int ? n_int : 1) * 2 * 8, &dt));
+    CHK(scratch_get(c, 3, (size_t)(n_int ? n_int : 1) * 2 * 16 * 8, &dP));
+    CHK(scratch_get(c, 4, 4 * 8, &dpr));
+    CHK(scratch_get(c, 5, 8, &dout));
+    HIPCHK(c, hipMemcpyAsync(dnodes, leaves, (size_t)n_leaves * S * 4 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dpr, prior4, 4 * 8, hipMemcpyHostToDevice, c->stream));
+    if (n_int) {
+        HIPCHK(c, hipMemcpyAsync(dorder, order.data(), order.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(dt, ts.data(), ts.size() * 8, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(pk_expm_batched, dim3(cdiv(2 * n_int, 64)), dim3(64), 0, c->stream, c->d_Q, (const double*)dt,
+                           2 * n_int, c->jc, (double*)dP);
+        CHK(launch_check(c, "pk_expm_batched"));
+        hipLaunchKernelGGL(pk_tree_prune, dim3(cdiv(S, 256)), dim3(256), 0, c->stream, (double*)dnodes,
+                           (const int32_t*)dorder, n_int, (const double*)dP, S);
+        CHK(launch_check(c, "pk_tree_prune"));
+    }
+    const double* droot = (const double*)dnodes + (size_t)root * S * 4;
+    hipLaunchKernelGGL(pk_row_loglik, dim3(1), dim3(PK_COLS), 0, c->stream, droot, (const double*)dpr, S, (double*)dout);
+    CHK(launch_check(c, "pk_row_loglik"));
+    HIPCHK(c, hipMemcpyAsync(out_loglik, dout, 8, hipMemcpyDeviceToHost, c->stream));
+    if (root_data) HIPCHK(c, hipMemcpyAsync(root_data, droot, (size_t)S * 4 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_resample(phylo_ctx* c, const double* logw, int K, uint64_t seed, uint32_t step, int64_t* idx) {
+    CHK(bind(c));
+    if (K < 0) return fail(c, PHYLO_EINVAL, "negative K");
+    if (K == 0) return PHYLO_OK;
+    if (!logw || !idx) return fail(c, PHYLO_EINVAL, "NULL pointer");
+    void *dw, *dcdf, *didx;
+    CHK(scratch_get(c, 0, (size_t)K * 8, &dw));
+    CHK(scratch_get(c, 1, (size_t)K * 8, &dcdf));
+    CHK(scratch_get(c, 2, (size_t)K * 8, &didx));
+    HIPCHK(c, hipMemcpyAsync(dw, logw, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_SCAN_THREADS), 0, c->stream, (const double*)dw, K,
+                       (uint64_t*)dcdf, (double*)nullptr);
+    CHK(launch_check(c, "pk_resample_scan"));
+    hipLaunchKernelGGL(pk_resample_search, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, (const uint64_t*)dcdf, K, K, 0, seed,
+                       step, (int64_t*)didx);
+    CHK(launch_check(c, "pk_resample_search"));
+    HIPCHK(c, hipMemcpyAsync(idx, didx, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_log_zsmc(phylo_ctx* c, const double* logw, int R, int K, double* out) {
+    CHK(bind(c));
+    if (R < 0 || K < 1 || !out || (R > 0 && !logw)) return fail(c, PHYLO_EINVAL, "bad arguments to phylo_log_zsmc");
+    void *dw, *dlse;
+    CHK(scratch_get(c, 0, (size_t)(R ? R : 1) * K * 8, &dw));
+    CHK(scratch_get(c, 1, (size_t)(R + 1) * 8, &dlse));
+    if (R) HIPCHK(c, hipMemcpyAsync(dw, logw, (size_t)R * K * 8, hipMemcpyHostToDevice, c->stream));
+    for (int r = 0; r < R; ++r) {
+        hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_SCAN_THREADS), 0, c->stream, (const double*)dw + (size_t)r * K, K,
+                           (uint64_t*)nullptr, (double*)dlse + r);
+        CHK(launch_check(c, "pk_resample_scan"));
+    }
+    hipLaunchKernelGGL(pk_logz_total, dim3(1), dim3(64), 0, c->stream, (const double*)dlse, R, (double*)dlse + R);
+    CHK(launch_check(c, "pk_logz_total"));
+    HIPCHK(c, hipMemcpyAsync(out, (double*)dlse + R, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
+    CHK(bind(c));
+    (void)M;
+    if (!c->have_leaves || !c->have_model)
+        return fail(c, PHYLO_ESTATE, "phylo_set_leaves and phylo_set_model must be called before a sweep");
+    if (flags & PHYLO_TWISTING) return fail(c, PHYLO_EINVAL, "PHYLO_TWISTING is not implemented in this build");
+    const int N = c->N, K = c->K, Kl = c->Kloc, S = c->S, R = N - 1;
+    const bool timek = (flags & PHYLO_TIME_KERNELS) != 0;
+    if (timek && (int)c->kev.size() < 2 * R) {
+        while ((int)c->kev.size() < 2 * R) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreate(&e));
+            c->kev.push_back(e);
+        }
+    }
+    int launches = 0;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    hipLaunchKernelGGL(pk_sweep_draws, dim3(cdiv((long)R * Kl, 64)), dim3(64), 0, c->stream, c->d_Q, c->d_lam_l, c->d_lam_r,
+                       c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat);
+    CHK(launch_check(c, "pk_sweep_draws"));
+    hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream, c->d_roots[0], c->d_cnt[0], K, N);
+    CHK(launch_check(c, "pk_init_tables"));
+    launches += 2;
+    const double ll_tilde0 = pm_log(1.0 / (double)K);      // vcsmc.py:422
+    for (int r = 0; r < R; ++r) {
+        const int cur = r & 1, nxt = cur ^ 1;
+        if (r > 0) {
+            CHK(phylo_comm_gather_rank(c->comm, c->d_logw + (size_t)(r - 1) * K, c->d_ll + (size_t)(r - 1) * K,
+                                       c->d_nodell + N + (size_t)(r - 1) * K, K, c->stream, &c->err));
+            hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_SCAN_THREADS), 0, c->stream,
+                               (const double*)(c->d_logw + (size_t)(r - 1) * K), K, c->d_cdf, c->d_lse + (r - 1));
+            CHK(launch_check(c, "pk_resample_scan"));
+            ++launches;
+        }
+        pk_book_args b{};
+        b.r = r; b.n = N - r; b.N = N; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
+        b.seed = seed; b.flags = flags;
+        b.roots_old = c->d_roots[cur]; b.cnt_old = c->d_cnt[cur];
+        b.roots_new = c->d_roots[nxt]; b.cnt_new = c->d_cnt[nxt];
+        b.cdf = c->d_cdf;
+        b.ll_prev = r > 0 ? c->d_ll + (size_t)(r - 1) * K : nullptr;
+        b.nodell = c->d_nodell;
+        b.ldf = c->d_ldf; b.ldf_n = N;
+        b.bl = c->d_bl; b.br = c->d_br;
+        b.lam_l = c->h_lam_l[r]; b.lam_r = c->h_lam_r[r];
+        b.loglam_l = pm_log(b.lam_l); b.loglam_r = pm_log(b.lam_r);
+        b.ll_tilde0 = ll_tilde0;
+        b.child = c->d_child; b.aux = c->d_aux; b.merges = c->d_merges; b.ancestors = c->d_anc;
+        hipLaunchKernelGGL(pk_rank_book, dim3(cdiv(K, 128)), dim3(128), 0, c->stream, b);
+        CHK(launch_check(c, "pk_rank_book"));
+        pk_merge_args m{};
+        m.leaves = c->d_leaves; m.pool = c->d_pool; m.child = c->d_child;
+        m.Pmat = c->d_Pmat + (size_t)r * Kl * 32;
+        m.pi = c->d_pi; m.nodell = c->d_nodell; m.aux = c->d_aux;
+        m.logw_r = c->d_logw + (size_t)r * K + c->k0;
+        m.ll_r = c->d_ll + (size_t)r * K + c->k0;
+        m.N = N; m.S = S; m.r = r; m.K = K; m.Kloc = Kl; m.k0 = c->k0;
+        if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r], c->stream));
+        hipLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, m);
+        CHK(launch_check(c, "pk_rank_merge"));
+        if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r + 1], c->stream));
+        launches += 2;
+    }
+    CHK(phylo_comm_gather_rank(c->comm, c->d_logw + (size_t)(R - 1) * K, c->d_ll + (size_t)(R - 1) * K,
+                               c->d_nodell + N + (size_t)(R - 1) * K, K, c->stream, &c->err));
+    hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_SCAN_THREADS), 0, c->stream,
+                       (const double*)(c->d_logw + (size_t)(R - 1) * K), K, (uint64_t*)nullptr, c->d_lse + (R - 1));
+    CHK(launch_check(c, "pk_resample_scan"));
+    hipLaunchKernelGGL(pk_logz_total, dim3(1), dim3(64), 0, c->stream, (const double*)c->d_lse, R, c->d_lse + R);
+    CHK(launch_check(c, "pk_logz_total"));
+    launches += 2;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->swept = true;
+    c->last_flags = flags;
+    c->n_merge_events = timek ? R : 0;
+    c->stats.n_launches = launches;
+    c->stats.units = (double)Kl * S * R;
+    c->stats.alg_bytes = 96.0 * c->stats.units;
+    return PHYLO_OK;
+}
+
+int phylo_synchronize(phylo_ctx* c) {
+    CHK(bind(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_sweep_fetch(phylo_ctx* c, double* log_weights, double* log_lik, double* lbranch, double* rbranch,
+                      int32_t* merges, int64_t* ancestors, double* logZ, phylo_stats* perf) {
+    CHK(bind(c));
+    if (!c->swept) return fail(c, PHYLO_ESTATE, "no sweep has been run");
+    const size_t R = (size_t)c->N - 1, K = c->K, Kl = c->Kloc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // log_weights / log_lik are stored with global columns; hand back this rank's columns
+    if (log_weights)
+        HIPCHK(c, hipMemcpy2D(log_weights, Kl * 8, c->d_logw + c->k0, K * 8, Kl * 8, R, hipMemcpyDeviceToHost));
+    if (log_lik) HIPCHK(c, hipMemcpy2D(log_lik, Kl * 8, c->d_ll + c->k0, K * 8, Kl * 8, R, hipMemcpyDeviceToHost));
+    if (lbranch) HIPCHK(c, hipMemcpy(lbranch, c->d_bl, R * Kl * 8, hipMemcpyDeviceToHost));
+    if (rbranch) HIPCHK(c, hipMemcpy(rbranch, c->d_br, R * Kl * 8, hipMemcpyDeviceToHost));
+    if (merges) HIPCHK(c, hipMemcpy(merges, c->d_merges, R * Kl * 2 * 4, hipMemcpyDeviceToHost));
+    if (ancestors && R > 1) HIPCHK(c, hipMemcpy(ancestors, c->d_anc, (R - 1) * Kl * 8, hipMemcpyDeviceToHost));
+    if (logZ) HIPCHK(c, hipMemcpy(logZ, c->d_lse + R, 8, hipMemcpyDeviceToHost));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->stats.sweep_ms = ms;
+    c->stats.merge_ms = 0.0;
+    c->stats.merge_launches = c->n_merge_events;
+    for (int r = 0; r < c->n_merge_events; ++r) {
+        float km = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&km, c->kev[2 * r], c->kev[2 * r + 1]));
+        c->stats.merge_ms += km;
+    }
+    if (perf) *perf = c->stats;
+    return PHYLO_OK;
+}
+
+int phylo_sweep(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, double* log_weights, double* log_lik,
+                double* lbranch, double* rbranch, int32_t* merges, int64_t* ancestors, double* logZ,
+                phylo_stats* perf) {
+    CHK(phylo_sweep_async(c, seed, flags, M));
+    return phylo_sweep_fetch(c, log_weights, log_lik, lbranch, rbranch, merges, ancestors, logZ, perf);
+}
+
+int phylo_sweep_node(phylo_ctx* c, int r, int k, double* out) {
+    CHK(bind(c));
+    if (!c->swept) return fail(c, PHYLO_ESTATE, "no sweep has been run");
+    if (r < 0 || r >= c->N - 1 || k < 0 || k >= c->Kloc || !out) return fail(c, PHYLO_EINVAL, "bad (r, k)");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t node_sz = (size_t)c->S * 4;
+    HIPCHK(c, hipMemcpy(out, c->d_pool + ((size_t)r * c->Kloc + k) * node_sz, node_sz * 8, hipMemcpyDeviceToHost));
+    return PHYLO_OK;
+}
+
+int phylo_math_probe(phylo_ctx* c, int op, const double* x, const double* y, int n, double* out) {
+    CHK(bind(c));
+    if (n < 0 || (n > 0 && (!x || !y || !out))) return fail(c, PHYLO_EINVAL, "bad arguments");
+    if (n == 0) return PHYLO_OK;
+    void *dx, *dy, *dout;
+    CHK(scratch_get(c, 0, (size_t)n * 8, &dx));
+    CHK(scratch_get(c, 1, (size_t)n * 8, &dy));
+    CHK(scratch_get(c, 2, (size_t)n * 8, &dout));
+    HIPCHK(c, hipMemcpyAsync(dx, x, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dy, y, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pk_math_probe, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, op, (const double*)dx, (const double*)dy, n,
+                       (double*)dout);
+    CHK(launch_check(c, "pk_math_probe"));
+    HIPCHK(c, hipMemcpyAsync(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+// ---- multi-GPU --------------------------------------------------------------------------------
+int phylo_comm_unique_id(char id[PHYLO_COMM_ID_BYTES]) {
+    std::string err;
+    int rc = phylo_comm_make_id(id, &err);
+    if (rc != PHYLO_OK) g_last_error = err;
+    return rc;
+}
+
+int phylo_comm_init(phylo_ctx* c, int rank, int world, const char id[PHYLO_COMM_ID_BYTES]) {
+    CHK(bind(c));
+    if (world < 1 || rank < 0 || rank >= world || !id) return fail(c, PHYLO_EINVAL, "bad rank/world");
+    if (c->K % world != 0) return fail(c, PHYLO_EINVAL, "K = %d is not divisible by world = %d", c->K, world);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = phylo_comm_setup(&c->comm, rank, world, id, &c->err);
+    if (rc != PHYLO_OK) return rc;
+    c->rank = rank;
+    c->world = world;
+    c->Kloc = c->K / world;
+    c->k0 = rank * c->Kloc;
+    c->swept = false;
+    CHK(alloc_sweep_state(c));
+    CHK(refresh_leaf_ll(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_comm_max(phylo_ctx* c, double* value) {
+    CHK(bind(c));
+    if (!value) return fail(c, PHYLO_EINVAL, "value is NULL");
+    return phylo_comm_allreduce_max(c->comm, value, c->stream, &c->err);
+}
+
+int phylo_comm_barrier(phylo_ctx* c) {
+    double v = 0.0;
+    return phylo_comm_max(c, &v);
+}
+
+}  // extern "C"

@@ -1,0 +1,266 @@
+"""GPU parity: the HIP path (through the C ABI, phylo_amd/_ffi.py) against the CPU oracle on the same
+seeded inputs.  Bit-exact for everything the arithmetic contract covers (resampling indices, merges,
+partials, log-weights, log Z-hat); golden fixtures from the reference's csmc.py at fp tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+from oracle import cpu_ref as O
+from phylo_amd import _ffi
+from phylo_amd.datasets import load_dataset, synthetic_alignment
+
+pytestmark = pytest.mark.gpu
+
+PI = np.full((1, 4), 0.25)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bit_equal(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, what
+    neq = bits(a) != bits(b)
+    # NaN payloads aside, every bit must match
+    both_nan = np.isnan(a) & np.isnan(b)
+    bad = neq & ~both_nan
+    assert not bad.any(), "%s: %d of %d values differ; first: gpu=%r cpu=%r" % (
+        what, bad.sum(), bad.size, a[bad][:1], b[bad][:1])
+
+
+def make_ctx(genome, K, Q, lam=10.0, jc=False, pi=PI):
+    N, S, _ = genome.shape
+    ctx = _ffi.Context(K, N, S)
+    ctx.set_leaves(genome)
+    ctx.set_model(Q, pi, np.full(N - 1, lam), np.full(N - 1, lam), jc69_closed_form=jc)
+    return ctx
+
+
+@pytest.fixture(scope="module")
+def primate():
+    return load_dataset('primate_data')['genome']
+
+
+@pytest.fixture(scope="module")
+def small():
+    return load_dataset('primate_data_wang')['genome']
+
+
+def test_device_arithmetic_contract(small):
+    """exp / log / division / fma on the GPU are bit-identical to the CPU statement of the contract."""
+    ctx = make_ctx(small[:3, :16], 2, O.jc_Q())
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-745, 709, 100000), [0.0, -0.0, 1e-300, -1e-300, 709.7, -745.1, np.inf, -np.inf]])
+    assert_bit_equal(ctx.math_probe(0, x), CO.math_probe(0, x), "exp")
+    x = np.concatenate([np.exp(rng.uniform(-744, 709, 100000)), rng.uniform(0.5, 2, 50000),
+                        [0.0, 1.0, 5e-324, 2.2e-308, np.inf, -1.0]])
+    assert_bit_equal(ctx.math_probe(1, x), CO.math_probe(1, x), "log")
+    a, b = rng.normal(size=200000) * 10.0 ** rng.integers(-200, 200, 200000), rng.normal(size=200000)
+    assert_bit_equal(ctx.math_probe(2, a, b), CO.math_probe(2, a, b), "div")
+    assert_bit_equal(ctx.math_probe(3, a, b), CO.math_probe(3, a, b), "fma")
+    ctx.close()
+
+
+def test_expm_batched_bit_exact_and_vs_scipy(golden_dir, small):
+    ex = np.load(os.path.join(golden_dir, "expm_tables.npz"))
+    t = np.concatenate([ex['t'], np.random.default_rng(1).exponential(0.1, 500)])
+    for q in ('csmc', 'jc', 'gtr_init', 'rand0', 'rand1', 'rand2'):
+        ctx = make_ctx(small[:3, :16], 2, ex['Q/' + q])
+        P = ctx.expm_batched(t)
+        assert_bit_equal(P, CO.expm_batched(ex['Q/' + q], t), "expm " + q)
+        np.testing.assert_allclose(P[:len(ex['t'])], ex['P/' + q], rtol=0, atol=1e-14)   # scipy.linalg.expm
+        ctx.close()
+    ctx = make_ctx(small[:3, :16], 2, ex['Q/jc'], jc=True)
+    P = ctx.expm_batched(t)
+    assert_bit_equal(P, CO.expm_batched(ex['Q/jc'], t, jc=True), "jc closed form")
+    np.testing.assert_allclose(P[:len(ex['t'])], ex['P/jc'], rtol=0, atol=3e-15)
+    assert ctx.expm_batched(np.zeros(0)).shape == (0, 4, 4)                                # empty input
+    ctx.close()
+
+
+def test_cond_likelihood_K_vs_oracle_and_reference_formula(primate):
+    rng = np.random.default_rng(2)
+    Q = O.get_Q(rng.normal(size=(4, 4)))
+    for K, S in [(1, 1), (7, 130), (33, 898), (5, 257)]:       # ragged: S not a multiple of 256, S = 1
+        g = primate[:, :S]
+        li, ri = rng.integers(0, 12, K), rng.integers(0, 12, K)
+        l = g[li] * rng.uniform(0.1, 1.0, (K, S, 1))           # not just one-hot rows
+        r = g[ri]
+        tl, tr = rng.exponential(0.1, K), rng.exponential(0.1, K)
+        ctx = make_ctx(primate[:, :S], 4, Q)
+        out = ctx.cond_likelihood_K(l, r, tl, tr)
+        assert_bit_equal(out, CO.cond_likelihood_K(Q, l, r, tl, tr), "cond_likelihood_K")
+        np.testing.assert_allclose(out, O.broadcast_conditional_likelihood_K(Q, l, r, tl, tr), rtol=1e-12)
+        ctx.close()
+
+
+def test_forest_loglik_vs_oracle(primate):
+    rng = np.random.default_rng(3)
+    K, X, S = 9, 5, 898
+    core = primate[rng.integers(0, 12, (K, X))] * rng.uniform(0.2, 1.0, (K, X, S, 1))
+    rec = rng.integers(1, 6, (K, X)).astype(np.int32)
+    ctx = make_ctx(primate, 4, O.jc_Q())
+    out = ctx.forest_loglik(core, rec)
+    assert_bit_equal(out, CO.forest_loglik(PI, core, rec), "forest_loglik")
+    np.testing.assert_allclose(out, O.compute_forest_posterior(PI, core, rec), rtol=1e-12)
+    # leaves only: S log(1/4) per non-gap leaf, gaps contribute log 1 = 0
+    leaf = ctx.forest_loglik(primate[None, :, :, :], np.ones((1, 12), dtype=np.int32))
+    n_nongap = int((primate.sum(axis=2) == 1).sum())
+    assert leaf[0] == pytest.approx(n_nongap * np.log(0.25), rel=1e-13)
+    ctx.close()
+
+
+def test_tree_loglik_golden_from_reference(golden_dir):
+    nodes = np.load(os.path.join(golden_dir, "csmc_nodes.npz"))
+    prior = np.ones(4) / 4
+    for tag in nodes['cases']:
+        dname, shape, qname = str(tag).split('/')
+        g = nodes['genome/' + dname]
+        ctx = make_ctx(g, 2, nodes['Q/' + qname])
+        la, ra = nodes[tag + '/left'], nodes[tag + '/right']
+        ll, data = ctx.tree_loglik(la, ra, nodes[tag + '/bl'], nodes[tag + '/br'], int(nodes[tag + '/root']), g, prior)
+        np.testing.assert_allclose(data, nodes[tag + '/root_data'], rtol=1e-12, atol=0)
+        assert ll == pytest.approx(float(nodes[tag + '/loglik']), rel=1e-12)
+        ll_c, data_c = CO.tree_loglik(nodes['Q/' + qname], prior, la, ra, nodes[tag + '/bl'], nodes[tag + '/br'],
+                                      int(nodes[tag + '/root']), g)
+        assert_bit_equal(data, data_c, "tree root data " + str(tag))
+        assert_bit_equal(ll, ll_c, "tree loglik " + str(tag))
+        ctx.close()
+
+
+def test_resample_bit_exact_and_edge_cases(small):
+    ctx = make_ctx(small[:3, :16], 2, O.jc_Q())
+    rng = np.random.default_rng(4)
+    for K in (1, 2, 255, 256, 1000, 2048, 5000):
+        for scale in (0.5, 30.0, 400.0):
+            lw = rng.normal(scale=scale, size=K) - 6000.0
+            idx = ctx.resample(lw, seed=11, step=3)
+            np.testing.assert_array_equal(idx, CO.resample(lw, 11, 3))
+            np.testing.assert_array_equal(idx, O.resample_indices(lw, 11, 3))
+            assert idx.min() >= 0 and idx.max() < K
+    lw = np.full(64, -np.inf); lw[17] = -5.0                       # one survivor
+    assert (ctx.resample(lw, 1, 1) == 17).all()
+    lw = rng.normal(size=300); lw[::7] = np.nan                    # NaN weights never selected
+    idx = ctx.resample(lw, 5, 2)
+    np.testing.assert_array_equal(idx, CO.resample(lw, 5, 2))
+    assert not np.isin(idx, np.arange(0, 300, 7)).any()
+    lw = np.full(50, -np.inf)                                      # degenerate: uniform
+    np.testing.assert_array_equal(ctx.resample(lw, 5, 2), CO.resample(lw, 5, 2))
+    # log Z
+    lw = rng.normal(scale=20, size=(11, 777)) - 500
+    z = ctx.log_zsmc(lw)
+    assert_bit_equal(z, CO.log_zsmc(lw), "log_zsmc")
+    assert z == pytest.approx(O.compute_log_ZSMC(lw), rel=1e-13)
+    assert ctx.log_zsmc(np.zeros((1, 32))) == pytest.approx(0.0, abs=1e-15)    # row 0 contributes 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("dataset,K,jc,seeds", [
+    ('primate_data_wang', 16, True, (0, 1, 2)),        # BASELINE config 0 shape: primates_small JC69 K=16
+    ('primate_data', 64, False, (0, 5)),               # GTR-init Q, gaps
+    ('primate_data', 300, True, (3,)),                 # K not a power of two
+])
+def test_sweep_bit_exact_vs_oracle(dataset, K, jc, seeds):
+    g = load_dataset(dataset)['genome']
+    N = g.shape[0]
+    Q = O.jc_Q() if jc else O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    ctx = make_ctx(g, K, Q, jc=jc)
+    for seed in seeds:
+        out = ctx.sweep(seed)
+        ref = CO.sweep(g, Q, PI, lam, lam, K, seed, jc=jc, want_nodes=True)
+        np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])     # indices bit-exact
+        np.testing.assert_array_equal(out['merges'], ref['merges'])
+        for key in ('left_branches', 'right_branches', 'log_likelihood', 'log_weights'):
+            assert_bit_equal(out[key], ref[key], key)
+        assert_bit_equal(out['logZ'], ref['logZ'], 'logZ')
+        for (r, k) in [(0, 0), (N - 2, K - 1), (N // 2, K // 3)]:
+            assert_bit_equal(ctx.sweep_node(r, k), ref['nodes'][r, k], "node partial (%d,%d)" % (r, k))
+        # against the independent NumPy oracle: same indices, log Z within 1e-9 relative
+        ref2 = O.sweep(g, Q, PI, lam, lam, K, seed)
+        np.testing.assert_array_equal(out['ancestors'], ref2['ancestors'])
+        assert out['logZ'] == pytest.approx(ref2['logZ'], rel=1e-9)
+    # determinism: same seed twice -> identical bits
+    a, b = ctx.sweep(7), ctx.sweep(7)
+    assert_bit_equal(a['log_weights'], b['log_weights'], "determinism")
+    ctx.close()
+
+
+def test_sweep_quirk_flag_and_trained_like_model():
+    """General (asymmetric) row-softmax Q, non-uniform pi, per-rank rates; Q1 flag off = log q."""
+    g = load_dataset('primate_data')['genome'][:7, 100:500]
+    N = 7
+    rng = np.random.default_rng(9)
+    Q = O.get_Q(rng.normal(size=(4, 4)))
+    pi = O.get_stationary_probs(rng.normal(size=4))
+    lam_l, lam_r = rng.uniform(3, 20, N - 1), rng.uniform(3, 20, N - 1)
+    K = 128
+    ctx = _ffi.Context(K, N, g.shape[1])
+    ctx.set_leaves(g)
+    ctx.set_model(Q, pi, lam_l, lam_r)
+    for flags in (1, 0):
+        out = ctx.sweep(21, flags=flags)
+        ref = CO.sweep(g, Q, pi, lam_l, lam_r, K, 21, flags=flags)
+        np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
+        assert_bit_equal(out['log_weights'], ref['log_weights'], "log_weights flags=%d" % flags)
+        assert_bit_equal(out['logZ'], ref['logZ'], "logZ")
+    ctx.close()
+
+
+def test_sweep_full_size_properties(primate):
+    """BASELINE sizes (primate.p, K=2048): size-independent properties instead of a slow oracle run."""
+    K, N = 2048, 12
+    Q = O.get_Q(O.init_y_q())
+    ctx = make_ctx(primate, K, Q)
+    out = ctx.sweep(0)
+    lw = out['log_weights']
+    assert np.isfinite(lw).all()
+    # log Z recomputed from the returned weights (checksum of checksums)
+    assert out['logZ'] == pytest.approx(O.compute_log_ZSMC(lw), rel=1e-13)
+    # resampling indices are reproducible from the returned weights alone
+    for r in (1, 5, 10):
+        np.testing.assert_array_equal(out['ancestors'][r - 1], O.resample_indices(lw[r - 1], 0, r))
+    # merges are valid, distinct root-table slots
+    for r in range(N - 1):
+        m = out['merges'][r]
+        assert (m[:, 0] != m[:, 1]).all() and m.min() >= 0 and m.max() < N - r
+    # the C oracle at full size on 3 rank-0 quantities is cheap: branch draws are particle-local
+    bl, br = O.branch_samples(K, 10.0, 10.0, 0, 0)
+    np.testing.assert_allclose(out['left_branches'][0], bl, rtol=1e-14)
+    # untrained level (K=512 about -6616 +- 53 for jc=false; larger K is higher)
+    assert -6900 < out['logZ'] < -6300
+    st = out['stats']
+    assert st['units'] == K * 898 * (N - 1) and st['alg_bytes'] == 96 * st['units']
+    ctx.close()
+
+
+def test_synthetic_large_sites():
+    """S = 5000 (many column iterations), N = 20."""
+    d = synthetic_alignment(20, 5000)
+    g = d['genome']
+    K = 24
+    lam = np.full(19, 10.0)
+    ctx = make_ctx(g, K, O.jc_Q(), jc=True)
+    out = ctx.sweep(2)
+    ref = CO.sweep(g, O.jc_Q(), PI, lam, lam, K, 2, jc=True)
+    np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
+    assert_bit_equal(out['log_weights'], ref['log_weights'], "log_weights")
+    ctx.close()
+
+
+def test_error_behaviour(small):
+    with pytest.raises(_ffi.PhyloError):
+        _ffi.Context(4, 1, 10)                      # N < 2
+    with pytest.raises(_ffi.PhyloError):
+        _ffi.Context(4, 5, 10, A=6)                 # A != 4
+    ctx = _ffi.Context(4, 9, 738)
+    with pytest.raises(_ffi.PhyloError) as e:
+        ctx.sweep(0)                                # before set_leaves / set_model
+    assert e.value.code == -6
+    ctx.set_leaves(small)
+    with pytest.raises(_ffi.PhyloError):
+        ctx.set_model(O.jc_Q(), PI, np.zeros(8), np.ones(8))     # non-positive rate
+    ctx.close()
