@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-site-likelihoods/sec of the CSMC sweep on MI355X (BASELINE.json metric).
+
+A "step" is one full sweep (N-1 rank events: draws, transition matrices, resampling, Felsenstein
+merges, weights, log Z-hat) over the alignment already resident in HBM.  Default workload: primate.p
+(N=12, S=898), jcmodel=false initial Q (GTR-init), K=2048 particles per GPU.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  No PyTorch is imported: the ranks are joined through RCCL inside
+libphylo_hip (phylo_comm_init); the 128-byte RCCL id travels through a file rendezvous on this node.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from phylo_amd import _ffi  # noqa: E402
+from phylo_amd import model as M  # noqa: E402
+from phylo_amd.datasets import load_dataset, synthetic_alignment  # noqa: E402
+from phylo_amd.rendezvous import exchange_comm_id  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--dataset', default='primate_data')
+    p.add_argument('--n_particles', type=int, default=2048, help='particles PER GPU')
+    p.add_argument('--jcmodel', default=False, type=lambda x: str(x).lower() == 'true')
+    p.add_argument('--synthetic', default=None, help='N,S : synthetic iid-uniform alignment instead of --dataset')
+    p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline duration')
+    return p.parse_args()
+
+
+def cpu_baseline(g, Q, pi, lam, jc, K_gpu, seconds):
+    """The C oracle (reference dataflow, OpenMP) timed on this host's cores on a bounded sample."""
+    from oracle import c_oracle as CO
+    N, S, _ = g.shape
+    # a one-GPU box offers a 16-core CPU share, whatever nproc says; oversubscribing only slows the baseline
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get('PHYLO_CPU_THREADS', '16'))))
+    CO.set_threads(cores)
+    t0 = time.perf_counter()
+    CO.sweep(g, Q, pi, lam, lam, 64, 0, jc=jc)
+    per_particle = (time.perf_counter() - t0) / 64
+    K = int(min(K_gpu, max(64, seconds / max(per_particle, 1e-9))))
+    K = 1 << (K.bit_length() - 1)
+    n = max(1, int(seconds / (per_particle * K)))
+    n = min(n, 8)
+    t0 = time.perf_counter()
+    for s in range(n):
+        CO.sweep(g, Q, pi, lam, lam, K, s, jc=jc)
+    dt = time.perf_counter() - t0
+    units = float(K) * S * (N - 1) * n
+    return {"value": units / dt, "unit": "particle-site-likelihoods/s", "cores": cores, "kind": "port",
+            "sample": "%d sweep(s) of the same alignment at K=%d (oracle/csrc/oracle.c, reference dataflow, %d OpenMP threads, %.1f s)"
+                      % (n, K, cores, dt)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs a launcher: python -m torch.distributed.run --nproc-per-node %d bench.py ..." % (a.gpus, a.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, a.gpus))
+    if a.synthetic:
+        n_taxa, n_sites = (int(v) for v in a.synthetic.split(','))
+        d = synthetic_alignment(n_taxa, n_sites)
+        wname = "synthetic %dx%d" % (n_taxa, n_sites)
+    else:
+        d = load_dataset(a.dataset)
+        wname = {'primate_data': 'primate.p', 'primate_data_wang': 'primates_small.p'}.get(a.dataset, a.dataset)
+    g = d['genome']
+    N, S, _ = g.shape
+    Q = M.jc_Q() if a.jcmodel else M.get_Q(M.init_y_q())
+    pi = M.get_stationary_probs(np.zeros(4) + 0.25)
+    lam = np.full(N - 1, 10.0)                       # branch_prior = log 10 (runner.py:38-41)
+    K_global = a.n_particles * world
+
+    ndev = _ffi.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    ctx = _ffi.Context(K_global, N, S, device=local_rank % ndev)
+    ctx.set_leaves(g)
+    ctx.set_model(Q, pi, lam, lam, jc69_closed_form=a.jcmodel)
+    if world > 1:
+        cid = exchange_comm_id(rank, world, _ffi.comm_unique_id if rank == 0 else None)
+        ctx.comm_init(rank, world, cid)
+
+    for w in range(a.warmup):
+        ctx.sweep_async(a.seed + 1000 + w)
+    ctx.synchronize()
+    ctx.comm_barrier()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        ctx.sweep_async(a.seed + s)
+    ctx.synchronize()
+    ctx.comm_barrier()
+    dt = time.perf_counter() - t0
+    dt = ctx.comm_max(dt)                            # max over ranks
+    last = ctx.sweep_fetch(arrays=False)
+
+    # dominant kernel (the Felsenstein merge): average launch duration from HIP events on the ctx stream
+    prof_sweeps = 3
+    merge_ms, merge_n = 0.0, 0
+    for s in range(prof_sweeps):
+        ctx.sweep_async(a.seed + s, flags=_ffi.FLAGS_DEFAULT | _ffi.TIME_KERNELS)
+        st = ctx.sweep_fetch(arrays=False)['stats']
+        merge_ms += st['merge_ms']
+        merge_n += st['merge_launches']
+    bytes_per_launch = 96.0 * ctx.K_local * S       # 2 child reads + 1 parent write, 32 B each, per (particle, site)
+    avg_s = merge_ms / merge_n * 1e-3
+    achieved = bytes_per_launch / avg_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get('workload') == wname and tj.get('K') == ctx.K_local:
+                traffic = tj.get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        units_per_step = float(K_global) * S * (N - 1)
+        line = {
+            "metric": "particle-site-likelihoods/sec", "value": units_per_step * a.steps / dt,
+            "unit": "particle-site-likelihoods/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if a.synthetic else "primate.p alignment (real sites), untrained model parameters",
+            "config": {"workload": "%s N=%d S=%d, %s, K=%d per GPU (K_total=%d), lambda=10, full sweep of %d rank events"
+                                   % (wname, N, S, "JC69" if a.jcmodel else "GTR-init (jcmodel=false)", a.n_particles, K_global, N - 1),
+                       "parallelism": "particles sharded over %d GPU(s), global resampling" % world},
+            "log_Z": last['logZ'],
+            "roofline": {"bound": "hbm", "kernel": "pk_rank_merge", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "alg_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6,
+                         "sweep_frac_of_peak": (96.0 * units_per_step / world) / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()

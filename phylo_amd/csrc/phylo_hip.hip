@@ -49,10 +49,12 @@ struct phylo_ctx {
     double* d_aux = nullptr;             // [Kloc][PK_AUX]
     double* d_lse = nullptr;             // [N-1] + total
     int32_t *d_roots[2] = {nullptr, nullptr}, *d_cnt[2] = {nullptr, nullptr};   // [K][N]
+    double* d_rootll[2] = {nullptr, nullptr};                                   // [K][N]
     int32_t* d_child = nullptr;          // [Kloc][2]
     int32_t* d_merges = nullptr;         // [(N-1)][Kloc][2]
     int64_t* d_anc = nullptr;            // [(N-2)][Kloc]
-    uint64_t* d_cdf = nullptr;           // [K]
+    uint64_t* d_cdf[2] = {nullptr, nullptr};   // [K], double-buffered across rank events
+    unsigned int* d_counter = nullptr;   // [N] arrival counters, one per rank event
     phylo_stats stats{};
     uint32_t last_flags = 0;
     int n_merge_events = 0;
@@ -133,13 +135,15 @@ int launch_check(phylo_ctx* ctx, const char* what) {
 void free_sweep_state(phylo_ctx* c) {
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
                     c->d_roots[0], c->d_roots[1], c->d_cnt[0], c->d_cnt[1], c->d_child, c->d_merges, c->d_anc,
-                    c->d_cdf};
+                    c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_pool = c->d_nodell = c->d_bl = c->d_br = c->d_Pmat = c->d_logw = c->d_ll = c->d_aux = c->d_lse = nullptr;
     c->d_roots[0] = c->d_roots[1] = c->d_cnt[0] = c->d_cnt[1] = c->d_child = c->d_merges = nullptr;
     c->d_anc = nullptr;
-    c->d_cdf = nullptr;
+    c->d_cdf[0] = c->d_cdf[1] = nullptr;
+    c->d_counter = nullptr;
+    c->d_rootll[0] = c->d_rootll[1] = nullptr;
 }
 
 int alloc_sweep_state(phylo_ctx* c) {
@@ -157,11 +161,14 @@ int alloc_sweep_state(phylo_ctx* c) {
     for (int i = 0; i < 2; ++i) {
         CHK(dalloc(c, &c->d_roots[i], K * N));
         CHK(dalloc(c, &c->d_cnt[i], K * N));
+        CHK(dalloc(c, &c->d_rootll[i], K * N));
     }
     CHK(dalloc(c, &c->d_child, Kl * 2));
     CHK(dalloc(c, &c->d_merges, R * Kl * 2));
     CHK(dalloc(c, &c->d_anc, (R > 0 ? R - 1 : 0) * Kl));
-    CHK(dalloc(c, &c->d_cdf, K));
+    CHK(dalloc(c, &c->d_cdf[0], K));
+    CHK(dalloc(c, &c->d_cdf[1], K));
+    CHK(dalloc(c, &c->d_counter, ((size_t)N + 3) & ~(size_t)3));
     return PHYLO_OK;
 }
 
@@ -432,7 +439,7 @@ int phylo_resample(phylo_ctx* c, const double* logw, int K, uint64_t seed, uint3
     CHK(scratch_get(c, 1, (size_t)K * 8, &dcdf));
     CHK(scratch_get(c, 2, (size_t)K * 8, &didx));
     HIPCHK(c, hipMemcpyAsync(dw, logw, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_SCAN_THREADS), 0, c->stream, (const double*)dw, K,
+    hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), 0, c->stream, (const double*)dw, K,
                        (uint64_t*)dcdf, (double*)nullptr);
     CHK(launch_check(c, "pk_resample_scan"));
     hipLaunchKernelGGL(pk_resample_search, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, (const uint64_t*)dcdf, K, K, 0, seed,
@@ -451,7 +458,7 @@ int phylo_log_zsmc(phylo_ctx* c, const double* logw, int R, int K, double* out) 
     CHK(scratch_get(c, 1, (size_t)(R + 1) * 8, &dlse));
     if (R) HIPCHK(c, hipMemcpyAsync(dw, logw, (size_t)R * K * 8, hipMemcpyHostToDevice, c->stream));
     for (int r = 0; r < R; ++r) {
-        hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_SCAN_THREADS), 0, c->stream, (const double*)dw + (size_t)r * K, K,
+        hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), 0, c->stream, (const double*)dw + (size_t)r * K, K,
                            (uint64_t*)nullptr, (double*)dlse + r);
         CHK(launch_check(c, "pk_resample_scan"));
     }
@@ -478,30 +485,28 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         }
     }
     int launches = 0;
+    const bool fused = (c->world == 1) && getenv("PHYLO_FUSE_TAIL");   // experiment: last merge workgroup runs the scan
+    const bool nt = getenv("PHYLO_NT_STORE") != nullptr;
+    const size_t lds = pk_book_lds_bytes(N);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(pk_sweep_draws, dim3(cdiv((long)R * Kl, 64)), dim3(64), 0, c->stream, c->d_Q, c->d_lam_l, c->d_lam_r,
+    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, (((size_t)N + 3) & ~(size_t)3) * sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(pk_sweep_draws, dim3(cdiv(2L * R * Kl, 64)), dim3(64), 0, c->stream, c->d_Q, c->d_lam_l, c->d_lam_r,
                        c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat);
     CHK(launch_check(c, "pk_sweep_draws"));
-    hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream, c->d_roots[0], c->d_cnt[0], K, N);
+    hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream, c->d_roots[0], c->d_cnt[0],
+                       c->d_rootll[0], (const double*)c->d_nodell, K, N);
     CHK(launch_check(c, "pk_init_tables"));
     launches += 2;
     const double ll_tilde0 = pm_log(1.0 / (double)K);      // vcsmc.py:422
     for (int r = 0; r < R; ++r) {
         const int cur = r & 1, nxt = cur ^ 1;
-        if (r > 0) {
-            CHK(phylo_comm_gather_rank(c->comm, c->d_logw + (size_t)(r - 1) * K, c->d_ll + (size_t)(r - 1) * K,
-                                       c->d_nodell + N + (size_t)(r - 1) * K, K, c->stream, &c->err));
-            hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_SCAN_THREADS), 0, c->stream,
-                               (const double*)(c->d_logw + (size_t)(r - 1) * K), K, c->d_cdf, c->d_lse + (r - 1));
-            CHK(launch_check(c, "pk_resample_scan"));
-            ++launches;
-        }
-        pk_book_args b{};
-        b.r = r; b.n = N - r; b.N = N; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
-        b.seed = seed; b.flags = flags;
+        pk_rank_args b{};
+        b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
+        b.seed = seed; b.flags = flags; b.fuse_tail = fused ? 1 : 0;
         b.roots_old = c->d_roots[cur]; b.cnt_old = c->d_cnt[cur];
         b.roots_new = c->d_roots[nxt]; b.cnt_new = c->d_cnt[nxt];
-        b.cdf = c->d_cdf;
+        b.rootll_old = c->d_rootll[cur]; b.rootll_new = c->d_rootll[nxt];
+        b.cdf = c->d_cdf[cur]; b.cdf_next = (r + 1 < R) ? c->d_cdf[nxt] : nullptr;
         b.ll_prev = r > 0 ? c->d_ll + (size_t)(r - 1) * K : nullptr;
         b.nodell = c->d_nodell;
         b.ldf = c->d_ldf; b.ldf_n = N;
@@ -509,30 +514,36 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         b.lam_l = c->h_lam_l[r]; b.lam_r = c->h_lam_r[r];
         b.loglam_l = pm_log(b.lam_l); b.loglam_r = pm_log(b.lam_r);
         b.ll_tilde0 = ll_tilde0;
-        b.child = c->d_child; b.aux = c->d_aux; b.merges = c->d_merges; b.ancestors = c->d_anc;
-        hipLaunchKernelGGL(pk_rank_book, dim3(cdiv(K, 128)), dim3(128), 0, c->stream, b);
+        b.leaves = c->d_leaves; b.pool = c->d_pool;
+        b.Pmat = c->d_Pmat + (size_t)r * Kl * 32;
+        b.pi = c->d_pi;
+        b.logw_r = c->d_logw + (size_t)r * K;
+        b.ll_r = c->d_ll + (size_t)r * K;
+        b.lse_r = c->d_lse + r;
+        b.merges = c->d_merges; b.ancestors = c->d_anc;
+        b.counter = c->d_counter + r;
+        b.child = c->d_child; b.aux = c->d_aux;
+        hipLaunchKernelGGL(pk_rank_book, dim3(K), dim3(64), lds, c->stream, b);
         CHK(launch_check(c, "pk_rank_book"));
-        pk_merge_args m{};
-        m.leaves = c->d_leaves; m.pool = c->d_pool; m.child = c->d_child;
-        m.Pmat = c->d_Pmat + (size_t)r * Kl * 32;
-        m.pi = c->d_pi; m.nodell = c->d_nodell; m.aux = c->d_aux;
-        m.logw_r = c->d_logw + (size_t)r * K + c->k0;
-        m.ll_r = c->d_ll + (size_t)r * K + c->k0;
-        m.N = N; m.S = S; m.r = r; m.K = K; m.Kloc = Kl; m.k0 = c->k0;
         if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r], c->stream));
-        hipLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, m);
+        if (nt) hipLaunchKernelGGL(pk_rank_merge<true>, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
+        else hipLaunchKernelGGL(pk_rank_merge<false>, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
         CHK(launch_check(c, "pk_rank_merge"));
         if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r + 1], c->stream));
         launches += 2;
+        if (!fused) {
+            CHK(phylo_comm_gather_rank(c->comm, c->d_logw + (size_t)r * K, c->d_ll + (size_t)r * K,
+                                       c->d_nodell + N + (size_t)r * K, K, c->stream, &c->err));
+            hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), 0, c->stream,
+                               (const double*)(c->d_logw + (size_t)r * K), K, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
+                               c->d_lse + r);
+            CHK(launch_check(c, "pk_resample_scan"));
+            ++launches;
+        }
     }
-    CHK(phylo_comm_gather_rank(c->comm, c->d_logw + (size_t)(R - 1) * K, c->d_ll + (size_t)(R - 1) * K,
-                               c->d_nodell + N + (size_t)(R - 1) * K, K, c->stream, &c->err));
-    hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_SCAN_THREADS), 0, c->stream,
-                       (const double*)(c->d_logw + (size_t)(R - 1) * K), K, (uint64_t*)nullptr, c->d_lse + (R - 1));
-    CHK(launch_check(c, "pk_resample_scan"));
     hipLaunchKernelGGL(pk_logz_total, dim3(1), dim3(64), 0, c->stream, (const double*)c->d_lse, R, c->d_lse + R);
     CHK(launch_check(c, "pk_logz_total"));
-    launches += 2;
+    ++launches;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->swept = true;
     c->last_flags = flags;

@@ -38,6 +38,15 @@ __device__ __forceinline__ void pk_store4(double* __restrict__ p, const double* 
     reinterpret_cast<double2*>(p)[1] = make_double2(v[2], v[3]);
 }
 
+// streaming (non-temporal) form: the new node is read again only by the few particles that survive the next
+// resampling, so it should not displace the leaves and live ancestors from L2
+typedef double pk_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pk_store4_nt(double* __restrict__ p, const double* v) {
+    pk_d2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    __builtin_nontemporal_store(a, reinterpret_cast<pk_d2*>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<pk_d2*>(p) + 1);
+}
+
 // one site of broadcast_conditional_likelihood_K (vcsmc.py:185-187): out_j = (sum_i L_i Pl_ij)(sum_i R_i Pr_ij)
 __device__ __forceinline__ void pk_merge_site(const double* L, const double* R, const double* Pl,
                                               const double* Pr, double* out) {
@@ -67,7 +76,7 @@ __device__ __forceinline__ double pk_site_lik(const double* pi, const double* x)
 // ------------------------------------------------------------------------------------------------
 // k1: batched transition matrices
 // ------------------------------------------------------------------------------------------------
-__global__ void pk_expm_batched(const double* __restrict__ Q, const double* __restrict__ t, int n, int jc,
+__global__ __launch_bounds__(64) void pk_expm_batched(const double* __restrict__ Q, const double* __restrict__ t, int n, int jc,
                                 double* __restrict__ P) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -79,29 +88,26 @@ __global__ void pk_expm_batched(const double* __restrict__ Q, const double* __re
     for (int j = 0; j < 16; ++j) P[(size_t)i * 16 + j] = p[j];
 }
 
-// all branch lengths and transition matrices of one sweep: thread per (rank event r, local particle k).
-// b = -log(U)/lambda_r (vcsmc.py:351-356); Pmat[r][k] = {P(b_l), P(b_r)}.
-__global__ void pk_sweep_draws(const double* __restrict__ Q, const double* __restrict__ lam_l,
-                               const double* __restrict__ lam_r, int jc, uint64_t seed, int R, int K, int k0,
-                               double* __restrict__ bl, double* __restrict__ br, double* __restrict__ Pmat) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R * K) return;
+// all branch lengths and transition matrices of one sweep: thread per (rank event r, local particle k,
+// side).  b = -log(U)/lambda_r (vcsmc.py:351-356); Pmat[r][k] = {P(b_l), P(b_r)}.
+__global__ __launch_bounds__(64) void pk_sweep_draws(const double* __restrict__ Q, const double* __restrict__ lam_l,
+                                                     const double* __restrict__ lam_r, int jc, uint64_t seed, int R, int K,
+                                                     int k0, double* __restrict__ bl, double* __restrict__ br,
+                                                     double* __restrict__ Pmat) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * R * K) return;
+    const int side = t & 1, i = t >> 1;
     const int r = i / K, k = i - r * K;
     const pm_u32x4 x = pm_philox4x32((uint32_t)(k0 + k), (uint32_t)r, PM_STREAM_BRANCH, 0u, seed);
-    const double tl = (-pm_log(pm_unit_oc(x.x, x.y))) / lam_l[r];
-    const double tr = (-pm_log(pm_unit_oc(x.z, x.w))) / lam_r[r];
-    bl[i] = tl;
-    br[i] = tr;
+    const double b = side ? (-pm_log(pm_unit_oc(x.z, x.w))) / lam_r[r] : (-pm_log(pm_unit_oc(x.x, x.y))) / lam_l[r];
+    (side ? br : bl)[i] = b;
     double q[16], p[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) q[j] = Q[j];
-    double* out = Pmat + (size_t)i * 32;
-    if (jc) pm_jc69(tl, p); else pm_expm4(q, tl, p);
+    if (jc) pm_jc69(b, p); else pm_expm4(q, b, p);
+    double* out = Pmat + (size_t)i * 32 + side * 16;
 #pragma unroll
     for (int j = 0; j < 16; ++j) out[j] = p[j];
-    if (jc) pm_jc69(tr, p); else pm_expm4(q, tr, p);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) out[16 + j] = p[j];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -194,73 +200,153 @@ __global__ void pk_tree_prune(double* __restrict__ nodes, const int32_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// k5: resampling.  One workgroup of 1024 threads: max, integer weights, canonical fp sum (for the
-// log-normaliser), inclusive integer prefix sum -> cdf[K] (uint64).  lse_out = m + log(sum) - log K.
+// k5: resampling.  One 256-thread workgroup: max, canonical fp sum of the weights (log-normaliser),
+// integer weights floor(exp(logw - max) 2^44) and their inclusive prefix sum -> cdf[K] (uint64).
+// lse_out = logsumexp_k(logw) - log K.  Loads are agent-scope (sc1) so the same code can run as the tail
+// of the merge kernel on weights other workgroups of the same launch have just published.
 // ------------------------------------------------------------------------------------------------
-#define PK_SCAN_THREADS 1024
-__global__ __launch_bounds__(PK_SCAN_THREADS) void pk_resample_scan(const double* __restrict__ logw, int K,
-                                                                    uint64_t* __restrict__ cdf,
-                                                                    double* __restrict__ lse_out) {
-    __shared__ double shd[PK_SCAN_THREADS / 64];
-    __shared__ uint64_t shu[PK_SCAN_THREADS / 64];
-    __shared__ double sh4[4];
+__device__ __forceinline__ double pk_ld_agent(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pk_st_agent(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct pk_scan_lds {
+    double d4[4];
+    unsigned long long u4[4];
+};
+
+// eight agent-scope (sc1) 8-byte loads issued back to back, ONE wait: hipcc waits after every relaxed
+// atomic load it emits itself, which serialises the round trips (cdna_hip_programming.md 5.7, form (i)).
+__device__ __forceinline__ void pk_ld8_agent(const double* const (&p)[8], double (&v)[8]) {
+    asm volatile(
+        "global_load_dwordx2 %0, %8, off sc1\n\t"
+        "global_load_dwordx2 %1, %9, off sc1\n\t"
+        "global_load_dwordx2 %2, %10, off sc1\n\t"
+        "global_load_dwordx2 %3, %11, off sc1\n\t"
+        "global_load_dwordx2 %4, %12, off sc1\n\t"
+        "global_load_dwordx2 %5, %13, off sc1\n\t"
+        "global_load_dwordx2 %6, %14, off sc1\n\t"
+        "global_load_dwordx2 %7, %15, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+        : "memory");
+}
+
+// load the tile [base, base + 2048) of logw, element base + tid + 256 j -> v[j]; out of range -> NaN
+__device__ __forceinline__ void pk_scan_tile(const double* logw, int K, int base, double (&v)[8]) {
+    const double* p[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = base + (int)threadIdx.x + PK_COLS * j;
+        p[j] = logw + (k < K ? k : K - 1);
+    }
+    pk_ld8_agent(p, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (base + (int)threadIdx.x + PK_COLS * j >= K) v[j] = pm_nan();
+}
+
+__device__ __forceinline__ void pk_scan_block(const double* logw, int K, uint64_t* __restrict__ cdf,
+                                              double* __restrict__ lse_out, pk_scan_lds* sh) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool one_tile = K <= 8 * PK_COLS;
+    double v[8];
     // ---- max (NaN counts as -inf)
     double m = -pm_inf();
-    for (int k = tid; k < K; k += PK_SCAN_THREADS) {
-        const double v = logw[k];
-        if (!pm_isnan(v) && v > m) m = v;
+    for (int base = 0; base < K; base += 8 * PK_COLS) {
+        pk_scan_tile(logw, K, base, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (!pm_isnan(v[j]) && v[j] > m) m = v[j];
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const double o = __shfl_xor(m, off, 64);
         m = o > m ? o : m;
     }
-    if (lane == 0) shd[wv] = m;
     __syncthreads();
-    m = shd[0];
+    if (lane == 0) sh->d4[wv] = m;
+    __syncthreads();
+    m = sh->d4[0];
 #pragma unroll
-    for (int i = 1; i < PK_SCAN_THREADS / 64; ++i) m = shd[i] > m ? shd[i] : m;
+    for (int i = 1; i < 4; ++i) m = sh->d4[i] > m ? sh->d4[i] : m;
     const bool all_bad = !(m > -pm_inf()) || m == pm_inf();
-    // ---- canonical fp sum of the weights, 256 columns
+    // ---- canonical fp sum (thread t = column t: elements t, t+256, ... in increasing order) and the
+    //      integer weights, staged in cdf[] itself
     double col = 0.0;
-    if (tid < PK_COLS) {
-        for (int k = tid; k < K; k += PK_COLS) {
-            const double v = logw[k];
-            const double w = all_bad ? 1.0 : (pm_isnan(v) ? 0.0 : pm_exp(v - m));
-            col = col + w;
-        }
+    for (int base = 0; base < K; base += 8 * PK_COLS) {
+        if (!one_tile) pk_scan_tile(logw, K, base, v);
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) col = col + __shfl_xor(col, off, 64);
-        if (lane == 0) sh4[wv] = col;
+        for (int j = 0; j < 8; ++j) {
+            const int k = base + tid + PK_COLS * j;
+            if (k < K) {
+                const double w = all_bad ? 1.0 : (pm_isnan(v[j]) ? 0.0 : pm_exp(v[j] - m));
+                col = col + w;
+                if (cdf) cdf[k] = all_bad ? 1ull : (uint64_t)(w * PM_CDF_SCALE);
+            }
+        }
     }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) col = col + __shfl_xor(col, off, 64);
     __syncthreads();
+    if (lane == 0) sh->d4[wv] = col;
+    __syncthreads();                                   // also orders the cdf[] staging stores (workgroup scope)
     if (tid == 0 && lse_out) {
-        const double sum = ((sh4[0] + sh4[1]) + sh4[2]) + sh4[3];
+        const double sum = ((sh->d4[0] + sh->d4[1]) + sh->d4[2]) + sh->d4[3];
         const double mm = all_bad ? 0.0 : m;
         *lse_out = (mm + pm_log(sum)) - pm_log((double)K);
     }
     if (!cdf) return;
-    // ---- integer inclusive scan; thread t owns the contiguous chunk [t*E, (t+1)*E)
-    const int E = (K + PK_SCAN_THREADS - 1) / PK_SCAN_THREADS;
-    const int lo = tid * E, hi = (lo + E < K) ? lo + E : K;
-    uint64_t local = 0;
-    for (int k = lo; k < hi; ++k) local += pm_weight_int(logw[k], m, all_bad);
-    uint64_t incl = local;
+    // ---- integer inclusive scan in place, tile by tile; inside a tile thread t owns the 8 contiguous
+    //      elements [base + 8t, base + 8t + 8) (independent 16-byte loads, one round trip)
+    unsigned long long carry = 0;
+    for (int base = 0; base < K; base += 8 * PK_COLS) {
+        const int lo = base + 8 * tid;
+        unsigned long long e[8];
+        if (lo + 8 <= K) {
+            const ulonglong2* q = reinterpret_cast<const ulonglong2*>(cdf + lo);
+            const ulonglong2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            e[0] = q0.x; e[1] = q0.y; e[2] = q1.x; e[3] = q1.y; e[4] = q2.x; e[5] = q2.y; e[6] = q3.x; e[7] = q3.y;
+        } else {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint64_t o = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += o;
+            for (int j = 0; j < 8; ++j) e[j] = (lo + j < K) ? cdf[lo + j] : 0ull;
+        }
+#pragma unroll
+        for (int j = 1; j < 8; ++j) e[j] += e[j - 1];
+        const unsigned long long local = e[7];
+        unsigned long long incl = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        __syncthreads();
+        if (lane == 63) sh->u4[wv] = incl;
+        __syncthreads();
+        unsigned long long run = carry + incl - local;
+        for (int i = 0; i < wv; ++i) run += sh->u4[i];
+        if (lo + 8 <= K) {
+            ulonglong2* q = reinterpret_cast<ulonglong2*>(cdf + lo);
+            q[0] = make_ulonglong2(run + e[0], run + e[1]);
+            q[1] = make_ulonglong2(run + e[2], run + e[3]);
+            q[2] = make_ulonglong2(run + e[4], run + e[5]);
+            q[3] = make_ulonglong2(run + e[6], run + e[7]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (lo + j < K) cdf[lo + j] = run + e[j];
+        }
+        carry += ((sh->u4[0] + sh->u4[1]) + sh->u4[2]) + sh->u4[3];
     }
-    if (lane == 63) shu[wv] = incl;
-    __syncthreads();
-    uint64_t wave_off = 0;
-    for (int i = 0; i < wv; ++i) wave_off += shu[i];
-    uint64_t run = wave_off + incl - local;
-    for (int k = lo; k < hi; ++k) {
-        run += pm_weight_int(logw[k], m, all_bad);
-        cdf[k] = run;
-    }
+}
+
+__global__ __launch_bounds__(PK_COLS) void pk_resample_scan(const double* logw, int K, uint64_t* __restrict__ cdf,
+                                                             double* __restrict__ lse_out) {
+    __shared__ pk_scan_lds sh;
+    pk_scan_block(logw, K, cdf, lse_out, &sh);
 }
 
 __device__ __forceinline__ int pk_cdf_search(const uint64_t* __restrict__ cdf, int K, uint64_t thr) {
@@ -270,6 +356,33 @@ __device__ __forceinline__ int pk_cdf_search(const uint64_t* __restrict__ cdf, i
         if (cdf[mid] > thr) hi = mid; else lo = mid + 1;
     }
     return lo < K ? lo : K - 1;
+}
+
+// the same search by one wave: 64 probes per step.  The first round's probe addresses do not depend on the
+// threshold, so `total` and the coarse probes travel together: 2 dependent round trips for K <= 4096.
+__device__ __forceinline__ int pk_cdf_search_wave(const uint64_t* __restrict__ cdf, int K, uint64_t R, int lane) {
+    int lo = 0, hi = K;             // invariant: answer in [lo, hi), cdf[hi-1] > thr
+    int step = (K + 63) >> 6;
+    int p = (lane + 1) * step - 1;
+    if (p > K - 1) p = K - 1;
+    const uint64_t total = cdf[K - 1];
+    uint64_t c = cdf[p];
+    const uint64_t thr = pm_mulhi64(R, total);
+    for (;;) {
+        const unsigned long long mask = __ballot(c > thr);
+        const int f = mask ? __ffsll((long long)mask) - 1 : 63;
+        int pf = lo + (f + 1) * step - 1;
+        if (pf > hi - 1) pf = hi - 1;
+        lo = lo + f * step;
+        hi = pf + 1;
+        if (lo >= hi) lo = hi - 1;
+        if (hi - lo <= 1) break;
+        step = (hi - lo + 63) >> 6;
+        p = lo + (lane + 1) * step - 1;
+        if (p > hi - 1) p = hi - 1;
+        c = cdf[p];
+    }
+    return lo;
 }
 
 __global__ void pk_resample_search(const uint64_t* __restrict__ cdf, int K, int n_draw, int k0, uint64_t seed,
@@ -293,138 +406,245 @@ __global__ void pk_logz_total(const double* __restrict__ lse, int R, double* __r
 // ------------------------------------------------------------------------------------------------
 // sweep state
 // ------------------------------------------------------------------------------------------------
-__global__ void pk_init_tables(int32_t* __restrict__ roots, int32_t* __restrict__ cnt, int K, int N) {
+__global__ void pk_init_tables(int32_t* __restrict__ roots, int32_t* __restrict__ cnt, double* __restrict__ rootll,
+                               const double* __restrict__ nodell, int K, int N) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K * N) return;
     roots[i] = i % N;
     cnt[i] = 1;
+    rootll[i] = nodell[i % N];      // sum_s log(pi . leaf[s]) of the leaf in that slot
 }
 
-struct pk_book_args {
-    int r, n, N, K /*global*/, Kloc, k0;
+// Arguments of one rank event.  Integer state (root tables) is indexed by GLOBAL particle; float state of
+// this rank's shard by local slot k = kg - k0.
+struct pk_rank_args {
+    int r, n, N, S, K /*global*/, Kloc, k0;
     uint64_t seed;
     uint32_t flags;
-    const int32_t* roots_old; const int32_t* cnt_old;     // [K global][N]
-    int32_t* roots_new; int32_t* cnt_new;                 // [K global][N]
-    const uint64_t* cdf;                                  // [K global] (r > 0)
-    const double* ll_prev;                                // ll[r-1][K global] (r > 0)
-    const double* nodell;                                 // per node id
-    const double* ldf; int ldf_n;                         // -log (2 max(c,2) - 3)!! table by leaf count
-    const double* bl; const double* br;                   // [R][Kloc] local slots
+    int fuse_tail;                                        // 1: last workgroup runs the next rank's scan
+    const int32_t* roots_old; const int32_t* cnt_old;     // [K][N]
+    int32_t* roots_new; int32_t* cnt_new;                 // [K][N]
+    const double* rootll_old; double* rootll_new;         // [K][N]: sum_s log(pi . x[s]) of the root in each slot
+    const uint64_t* cdf;                                  // [K] (r > 0): scan of log w_{r-1}
+    uint64_t* cdf_next;                                   // [K]: written by the fused tail
+    const double* ll_prev;                                // ll[r-1][K] (r > 0)
+    double* nodell;                                       // per node id
+    const double* ldf; int ldf_n;                         // log (2 max(c,2) - 3)!! by leaf count
+    const double* bl; const double* br;                   // [R][Kloc]
     double lam_l, lam_r, loglam_l, loglam_r, ll_tilde0;
-    int32_t* child;                                       // [Kloc][2]
-    double* aux;                                          // [Kloc][PK_AUX]
+    const double* leaves;                                 // [N][S][4]
+    double* pool;                                         // [(N-1)][Kloc][S][4]
+    const double* Pmat;                                   // [Kloc][32] of this rank
+    const double* pi;
+    double* logw_r; double* ll_r;                         // [K] rows (global columns)
+    double* lse_r;                                        // log-normaliser of THIS rank's weights (fused tail)
     int32_t* merges;                                      // [R][Kloc][2]
     int64_t* ancestors;                                   // [R-1][Kloc]
+    int32_t* child;                                       // [Kloc][2]: node ids merged at this rank event
+    double* aux;                                          // [Kloc][PK_AUX]: weight terms for the merge epilogue
+    unsigned int* counter;                                // arrival counter of this rank event (zeroed per sweep)
 };
 
-// Bookkeeping of one rank event for every particle of the GLOBAL population (thread per particle):
-// resampling index (vcsmc.py:285), adoption of the ancestor's root table (the tf.gather of :286-288,
-// on integer tables instead of partial likelihoods), uniform pair pick (:303-305), new root table
-// (:361-373), and the scalar terms of the weight (:376-392) that do not depend on the new node.
-// Integer state is replicated on every GPU; float outputs are written only for local slots.
-__global__ void pk_rank_book(const pk_book_args a) {
-    const int kg = blockIdx.x * blockDim.x + threadIdx.x;      // global particle
-    if (kg >= a.K) return;
-    const int n = a.n, N = a.N;
-    int anc = kg;
-    if (a.r > 0) {
-        const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_RESAMPLE, 0u, a.seed);
-        const uint64_t R = ((uint64_t)x.y << 32) | x.x;
-        anc = pk_cdf_search(a.cdf, a.K, pm_mulhi64(R, a.cdf[a.K - 1]));
-    }
-    const int32_t* ro = a.roots_old + (size_t)anc * N;
-    const int32_t* co = a.cnt_old + (size_t)anc * N;
-    // ---- keys of the n root slots
-    uint32_t key[PK_MAX_TAXA];
-    for (int b = 0; b < (n + 3) / 4; ++b) {
-        const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_PAIR, (uint32_t)b, a.seed);
-        key[b * 4 + 0] = x.x; key[b * 4 + 1] = x.y; key[b * 4 + 2] = x.z; key[b * 4 + 3] = x.w;
-    }
-    int il = 0;                                     // largest key, lower slot on ties
-    for (int i = 1; i < n; ++i) if (key[i] > key[il]) il = i;
-    int ir = (il == 0) ? 1 : 0;                     // second largest
-    for (int i = 0; i < n; ++i) if (i != il && i != ir && key[i] > key[ir]) ir = i;
-    // the loop above keeps the lower slot on ties only if ir started at the lowest candidate: it does.
-    const bool local = (kg >= a.k0) && (kg < a.k0 + a.Kloc);
-    const int k = kg - a.k0;
-    int32_t* rn = a.roots_new + (size_t)kg * N;
-    int32_t* cn = a.cnt_new + (size_t)kg * N;
-    // ---- remaining slots by ascending (key, slot); selection by repeated minimum
-    double sum_rem = 0.0, fprior = 0.0;
-    int vminus = 0;
-    uint64_t last = 0;                              // (key << 32 | slot) + 1 of the previous pick; 0 = none
-    for (int p = 0; p < n - 2; ++p) {
-        uint64_t best = ~0ull;
-        for (int i = 0; i < n; ++i) {
-            if (i == il || i == ir) continue;
-            const uint64_t c = (((uint64_t)key[i] << 32) | (uint32_t)i) + 1ull;
-            if (c > last && c < best) best = c;
+// LDS carve of the bookkeeping prologue (arrays of length N rounded up to a multiple of 4)
+struct pk_book_lds {
+    double *ord_ll, *ord_ldf, *hbl, *hbr, *anc_ll, *ldf;   // ldf: N+1 entries (n4 + 4 reserved)
+    uint32_t* key; int32_t *ro, *co, *ord_cnt;
+    double* aux; int32_t* misc;   // misc: [0] child l, [1] child r, [2] is_last, [3] ancestor
+};
+__host__ __device__ inline size_t pk_book_lds_bytes(int N) {
+    const size_t n4 = ((size_t)N + 3) & ~(size_t)3;
+    return (6 * n4 + 4) * 8 + PK_AUX * 8 + (4 * n4) * 4 + 16 /*misc*/;
+}
+__device__ __forceinline__ pk_book_lds pk_book_carve(char* base, int N) {
+    const size_t n4 = ((size_t)N + 3) & ~(size_t)3;
+    pk_book_lds L;
+    L.ord_ll = (double*)base;
+    L.ord_ldf = L.ord_ll + n4;
+    L.hbl = L.ord_ldf + n4;
+    L.hbr = L.hbl + n4;
+    L.anc_ll = L.hbr + n4;
+    L.ldf = L.anc_ll + n4;
+    L.aux = L.ldf + n4 + 4;
+    L.key = (uint32_t*)(L.aux + PK_AUX);
+    L.ro = (int32_t*)(L.key + n4);
+    L.co = L.ro + n4;
+    L.ord_cnt = L.co + n4;
+    L.misc = L.ord_cnt + n4;
+    return L;
+}
+
+// Bookkeeping of one rank event for ONE particle (global index kg), by the first wave of a workgroup;
+// every thread of the workgroup must call it (it contains workgroup barriers).
+//   resampling index (vcsmc.py:285) -> adoption of the ancestor's root table (the tf.gather of :286-288, on
+//   integer tables instead of partial likelihoods) -> uniform pair pick (:303-305) -> new root table
+//   (:361-373) -> the scalar terms of the weight that do not depend on the new node (:376-392).
+// `local`: the particle belongs to this rank's shard (float terms and outputs are produced).
+// Dependent global round trips: {cdf total + coarse probes, branch history, ldf table} -> {fine probes}
+// -> {ancestor's table rows, its log-likelihood}; everything after that runs out of LDS.
+__device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, bool local, const pk_book_lds& L) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool w0 = tid < 64;
+    const int n = a.n, N = a.N, k = kg - a.k0;
+    if (w0) {
+        // independent of the resampling outcome: issue first (slots >= 64 are copied further down)
+        const double hb_l0 = (local && lane <= a.r) ? a.bl[(size_t)lane * a.Kloc + k] : 0.0;
+        const double hb_r0 = (local && lane <= a.r) ? a.br[(size_t)lane * a.Kloc + k] : 0.0;
+        const double ldf0 = (lane <= a.ldf_n) ? a.ldf[lane] : 0.0;
+        int anc = kg;
+        if (a.r > 0) {
+            const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_RESAMPLE, 0u, a.seed);
+            const uint64_t R = ((uint64_t)x.y << 32) | x.x;
+            anc = pk_cdf_search_wave(a.cdf, a.K, R, lane);
         }
-        last = best;
-        const int slot = (int)((best - 1ull) & 0xffffffffull);
-        const int node = ro[slot];
-        const int c = co[slot];
-        rn[p] = node;
-        cn[p] = c;
-        if (local) sum_rem = sum_rem + a.nodell[node];
-        fprior = fprior + (-a.ldf[c < a.ldf_n ? c : a.ldf_n]);
-        vminus += c - (c == 1 ? 1 : 0);
+        const int32_t* ro = a.roots_old + (size_t)anc * N;
+        const int32_t* co = a.cnt_old + (size_t)anc * N;
+        const double* rl = a.rootll_old + (size_t)anc * N;
+        #pragma unroll 1
+        for (int i = lane; i < n; i += 64) { L.ro[i] = ro[i]; L.co[i] = co[i]; L.anc_ll[i] = rl[i]; }
+        if (lane == 0) {
+            L.misc[3] = anc;
+            if (local) L.aux[AUX_LL_TILDE] = (a.r > 0) ? a.ll_prev[anc] : a.ll_tilde0;
+        }
+        #pragma unroll 1
+        for (int b = lane; b < (n + 3) / 4; b += 64) {
+            const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_PAIR, (uint32_t)b, a.seed);
+            L.key[b * 4 + 0] = x.x; L.key[b * 4 + 1] = x.y; L.key[b * 4 + 2] = x.z; L.key[b * 4 + 3] = x.w;
+        }
+        if (lane <= a.r) { L.hbl[lane] = hb_l0; L.hbr[lane] = hb_r0; }
+        if (lane <= a.ldf_n) L.ldf[lane] = ldf0;
+        #pragma unroll 1
+        for (int j = lane + 64; j <= a.r; j += 64) {
+            L.hbl[j] = local ? a.bl[(size_t)j * a.Kloc + k] : 0.0;
+            L.hbr[j] = local ? a.br[(size_t)j * a.Kloc + k] : 0.0;
+        }
+        #pragma unroll 1
+        for (int j = lane + 64; j <= a.ldf_n; j += 64) L.ldf[j] = a.ldf[j];
     }
-    const int cl = ro[il], cr = ro[ir];
-    const int cnew = co[il] + co[ir];
-    rn[n - 2] = a.N + a.r * a.K + kg;               // id of the node this particle creates now
-    cn[n - 2] = cnew;
-    if (!local) return;
-    fprior = fprior + (-a.ldf[cnew < a.ldf_n ? cnew : a.ldf_n]);
-    vminus += cnew - (cnew == 1 ? 1 : 0);
-    a.child[k * 2 + 0] = cl;
-    a.child[k * 2 + 1] = cr;
-    a.merges[((size_t)a.r * a.Kloc + k) * 2 + 0] = il;
-    a.merges[((size_t)a.r * a.Kloc + k) * 2 + 1] = ir;
-    if (a.r > 0) a.ancestors[(size_t)(a.r - 1) * a.Kloc + k] = anc;
-    // ---- branch-length log-priors over the slot-attached history rows 0..r with THIS rank's rate (Q3)
-    double lp = 0.0, rp = 0.0;
-    for (int j = 0; j <= a.r; ++j) {
-        lp = lp + ((-a.lam_l) * a.bl[(size_t)j * a.Kloc + k] + a.loglam_l);
-        rp = rp + ((-a.lam_r) * a.br[(size_t)j * a.Kloc + k] + a.loglam_r);
+    __syncthreads();
+    if (w0) {
+        // largest key (lower slot on ties), then the second largest
+        unsigned long long best = 0ull;
+        #pragma unroll 1
+        for (int i = lane; i < n; i += 64) {
+            const unsigned long long c = ((unsigned long long)L.key[i] << 32) | (0xffffffffu - (uint32_t)i);
+            best = c > best ? c : best;
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_xor(best, off, 64);
+            best = o > best ? o : best;
+        }
+        const int il = (int)(0xffffffffu - (uint32_t)best);
+        best = 0ull;
+        #pragma unroll 1
+        for (int i = lane; i < n; i += 64) {
+            const unsigned long long c = ((unsigned long long)L.key[i] << 32) | (0xffffffffu - (uint32_t)i);
+            if (i != il) best = c > best ? c : best;
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = __shfl_xor(best, off, 64);
+            best = o > best ? o : best;
+        }
+        const int ir = (int)(0xffffffffu - (uint32_t)best);
+        // position of every remaining slot in ascending (key, slot) order
+        int32_t* rn = a.roots_new + (size_t)kg * N;
+        int32_t* cn = a.cnt_new + (size_t)kg * N;
+        double* rln = a.rootll_new + (size_t)kg * N;
+        #pragma unroll 1
+        for (int i = lane; i < n; i += 64) {
+            if (i == il || i == ir) continue;
+            const unsigned long long mine = ((unsigned long long)L.key[i] << 32) | (uint32_t)i;
+            int rank = 0;
+            #pragma unroll 1
+            for (int j = 0; j < n; ++j) {
+                const unsigned long long cj = ((unsigned long long)L.key[j] << 32) | (uint32_t)j;
+                rank += (j != il && j != ir && cj < mine) ? 1 : 0;
+            }
+            const int node = L.ro[i], c = L.co[i];
+            const double xll = L.anc_ll[i];
+            rn[rank] = node;
+            cn[rank] = c;
+            rln[rank] = xll;
+            L.ord_cnt[rank] = c;
+            L.ord_ll[rank] = xll;
+            L.ord_ldf[rank] = L.ldf[c < a.ldf_n ? c : a.ldf_n];
+        }
+        if (lane == 0) {
+            const int cnew = L.co[il] + L.co[ir];
+            rn[n - 2] = N + a.r * a.K + kg;           // id of the node this particle creates now
+            cn[n - 2] = cnew;
+            L.ord_cnt[n - 2] = cnew;
+            L.ord_ldf[n - 2] = L.ldf[cnew < a.ldf_n ? cnew : a.ldf_n];
+            L.misc[0] = L.ro[il];
+            L.misc[1] = L.ro[ir];
+            if (local) {
+                a.merges[((size_t)a.r * a.Kloc + k) * 2 + 0] = il;
+                a.merges[((size_t)a.r * a.Kloc + k) * 2 + 1] = ir;
+                if (a.r > 0) a.ancestors[(size_t)(a.r - 1) * a.Kloc + k] = L.misc[3];
+            }
+        }
     }
-    const double b_l = a.bl[(size_t)a.r * a.Kloc + k], b_r = a.br[(size_t)a.r * a.Kloc + k];
-    const double paren = ((a.loglam_l - a.lam_l * b_l) + a.loglam_r) - a.lam_r * b_r;
-    const double q = 1.0 / ((double)((n - 1) * n) / 2.0);      // 1 / ncr(n, 2), vcsmc.py:298
-    double* ax = a.aux + (size_t)k * PK_AUX;
-    ax[AUX_SUM_REM] = sum_rem;
-    ax[AUX_FPRIOR] = fprior;
-    ax[AUX_LPRIOR] = lp;
-    ax[AUX_RPRIOR] = rp;
-    ax[AUX_LL_TILDE] = (a.r > 0) ? a.ll_prev[anc] : a.ll_tilde0;
-    ax[AUX_PAREN] = paren;
-    ax[AUX_LOGV] = pm_log((double)vminus);
-    ax[AUX_Q] = (a.flags & 1u) ? q : pm_log(q);
+    __syncthreads();
+    if (tid == 0 && local) {                          // sequential sums, LDS operands only
+        double sum_rem = 0.0, fprior = 0.0;
+        int vminus = 0;
+        #pragma unroll 1
+        for (int p = 0; p < n - 2; ++p) sum_rem = sum_rem + L.ord_ll[p];
+        #pragma unroll 1
+        for (int p = 0; p < n - 1; ++p) {
+            const int c = L.ord_cnt[p];
+            fprior = fprior + (-L.ord_ldf[p]);
+            vminus += c - (c == 1 ? 1 : 0);
+        }
+        double lp = 0.0, rp = 0.0;                    // history rows 0..r with THIS rank's rate (quirk Q3)
+        #pragma unroll 1
+        for (int j = 0; j <= a.r; ++j) {
+            lp = lp + ((-a.lam_l) * L.hbl[j] + a.loglam_l);
+            rp = rp + ((-a.lam_r) * L.hbr[j] + a.loglam_r);
+        }
+        const double b_l = L.hbl[a.r], b_r = L.hbr[a.r];
+        const double q = 1.0 / ((double)((n - 1) * n) / 2.0);      // 1 / ncr(n, 2), vcsmc.py:298
+        L.aux[AUX_SUM_REM] = sum_rem;
+        L.aux[AUX_FPRIOR] = fprior;
+        L.aux[AUX_LPRIOR] = lp;
+        L.aux[AUX_RPRIOR] = rp;
+        L.aux[AUX_PAREN] = ((a.loglam_l - a.lam_l * b_l) + a.loglam_r) - a.lam_r * b_r;
+        L.aux[AUX_LOGV] = pm_log((double)vminus);
+        L.aux[AUX_Q] = (a.flags & 1u) ? q : pm_log(q);
+    }
+    __syncthreads();
+}
+
+// Bookkeeping kernel: one 64-thread workgroup (one wave) per GLOBAL particle.  Particles of this rank's
+// shard also get their child node ids and weight terms written for the merge kernel; for the others only the
+// replicated integer state (root tables) is advanced.
+__global__ __launch_bounds__(64) void pk_rank_book(const pk_rank_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int kg = blockIdx.x;
+    const pk_book_lds L = pk_book_carve(smem, a.N);
+    const bool local = kg >= a.k0 && kg < a.k0 + a.Kloc;
+    pk_book_particle(a, kg, local, L);
+    if (local && threadIdx.x < PK_AUX + 2) {
+        const int k = kg - a.k0;
+        if (threadIdx.x < PK_AUX) a.aux[(size_t)k * PK_AUX + threadIdx.x] = L.aux[threadIdx.x];
+        else a.child[k * 2 + (threadIdx.x - PK_AUX)] = L.misc[threadIdx.x - PK_AUX];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k2 + k3 + k8 (sweep form): one workgroup per local particle.  Reads the two child partials by node
-// id (leaves or pool), writes the new node's partial, reduces sum_s log(pi . new[s]) canonically, and
-// finishes log_likelihood_r and log w_r (vcsmc.py:376-392).
-//   algorithmic traffic: 2 x 32 B read + 32 B written per (particle, site)  = 96 B / unit.
+// The Felsenstein merge of one rank event, one workgroup (256 threads) per local particle:
+//   body      k2: the new node's partial likelihoods, out[s,:] = (L[s,:] P_l) * (R[s,:] P_r)
+//             k3: sum_s log(pi . out[s,:]) in the canonical order
+//   epilogue  k8: log_likelihood_r and log w_r (vcsmc.py:376-392)
+//   tail      the workgroup that finishes last scans the K weights for the next rank's resampling (k5)
+//   algorithmic traffic: 2 x 32 B read + 32 B written per (particle, site) = 96 B / unit.
 // ------------------------------------------------------------------------------------------------
-struct pk_merge_args {
-    const double* leaves;     // [N][S][4]
-    double* pool;             // [(N-1)][Kloc][S][4] local nodes
-    const int32_t* child;     // [Kloc][2]
-    const double* Pmat;       // [Kloc][32] of this rank
-    const double* pi;
-    double* nodell;           // per node id (global ids)
-    const double* aux;        // [Kloc][PK_AUX]
-    double* logw_r;           // [Kloc]
-    double* ll_r;             // [Kloc]
-    int N, S, r, K /*global*/, Kloc, k0;
-};
-
-__global__ __launch_bounds__(PK_COLS) void pk_rank_merge(const pk_merge_args a) {
-    __shared__ double sh4[4];
-    const int k = blockIdx.x;
+template <bool NT>
+__global__ __launch_bounds__(PK_COLS, 6) void pk_rank_merge(const pk_rank_args a) {
+    __shared__ pk_scan_lds scan_sh;
+    __shared__ int is_last;
+    const int k = blockIdx.x, kg = a.k0 + k;
     const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
     const size_t node_sz = (size_t)a.S * 4;
     // a child is a leaf (id < N) or a node of the local pool: id = N + rho*K + kappa
@@ -440,23 +660,33 @@ __global__ __launch_bounds__(PK_COLS) void pk_rank_merge(const pk_merge_args a) 
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     double col = 0.0;
     for (int s = threadIdx.x; s < a.S; s += PK_COLS) {
-        double L[4], R[4], o[4];
-        pk_load4(Lp + (size_t)s * 4, L);
-        pk_load4(Rp + (size_t)s * 4, R);
-        pk_merge_site(L, R, Pl, Pr, o);
-        pk_store4(out + (size_t)s * 4, o);
+        double Lv[4], Rv[4], o[4];
+        pk_load4(Lp + (size_t)s * 4, Lv);
+        pk_load4(Rp + (size_t)s * 4, Rv);
+        pk_merge_site(Lv, Rv, Pl, Pr, o);
+        if (NT) pk_store4_nt(out + (size_t)s * 4, o); else pk_store4(out + (size_t)s * 4, o);
         col = col + pm_log(pk_site_lik(pi, o));
     }
-    const double tot = pk_block_canon_sum(col, sh4);
+    const double tot = pk_block_canon_sum(col, scan_sh.d4);
     if (threadIdx.x == 0) {
         const double* ax = a.aux + (size_t)k * PK_AUX;
-        a.nodell[a.N + a.r * a.K + a.k0 + k] = tot;
         const double fl = ax[AUX_SUM_REM] + tot;
         const double ll = ((fl + ax[AUX_FPRIOR]) + ax[AUX_LPRIOR]) + ax[AUX_RPRIOR];
         const double lw = (((ll - ax[AUX_LL_TILDE]) - ax[AUX_PAREN]) + ax[AUX_LOGV]) - ax[AUX_Q];
-        a.ll_r[k] = ll;
-        a.logw_r[k] = lw;
+        a.nodell[a.N + a.r * a.K + kg] = tot;
+        a.rootll_new[(size_t)kg * a.N + (a.n - 2)] = tot;
+        a.ll_r[kg] = ll;
+        pk_st_agent(a.logw_r + kg, lw);                 // write-through: read by the tail of THIS launch
+        int last = 0;
+        if (a.fuse_tail) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = (ticket == (unsigned int)(a.Kloc - 1)) ? 1 : 0;
+        }
+        is_last = last;
     }
+    __syncthreads();
+    if (is_last) pk_scan_block(a.logw_r, a.K, a.cdf_next, a.lse_r, &scan_sh);
 }
 
 // arithmetic probe

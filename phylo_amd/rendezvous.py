@@ -1,0 +1,42 @@
+"""Out-of-band hand-off of the 128-byte RCCL unique id between the ranks of ONE node.
+
+torch.distributed.run gives every rank MASTER_ADDR/MASTER_PORT/RANK/WORLD_SIZE; its own store speaks a
+private protocol, and this package does not import PyTorch, so the id travels through a file that rank 0
+writes atomically under /tmp (single node by contract).  The directory name carries MASTER_PORT and the
+launcher's pid (all ranks share one parent), so back-to-back runs on the same port cannot see stale ids.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+
+def _dir():
+    tag = "%s_%s_%d" % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())
+    return os.path.join(os.environ.get('PHYLO_RDZV_DIR', '/tmp'), "phylo_rdzv_" + tag)
+
+
+def exchange_comm_id(rank, world, make_id, timeout=300.0):
+    """rank 0 calls make_id() and publishes it; every rank returns the same bytes."""
+    d = _dir()
+    path = os.path.join(d, "comm_id.bin")
+    if rank == 0:
+        cid = make_id()
+        os.makedirs(d, exist_ok=True)
+        tmp = path + ".tmp.%d" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(cid)
+        os.replace(tmp, path)
+        return cid
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                cid = f.read()
+            if len(cid) >= 128:
+                return cid
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise TimeoutError("rank %d: no RCCL id from rank 0 at %s after %.0f s" % (rank, path, timeout))
+        time.sleep(0.01)
