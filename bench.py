@@ -40,6 +40,8 @@ def parse():
     p.add_argument('--jcmodel', default=False, type=lambda x: str(x).lower() == 'true')
     p.add_argument('--synthetic', default=None, help='N,S : synthetic iid-uniform alignment instead of --dataset')
     p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--streams', type=int, default=0,
+                   help='independent sweeps kept in flight on separate HIP streams (0 = 3 on one GPU, 1 when sharded)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline duration')
     return p.parse_args()
@@ -62,7 +64,7 @@ def cpu_baseline(g, Q, pi, lam, jc, K_gpu, seconds):
     K = int(min(K_gpu, max(64, seconds / max(per_particle, 1e-9))))
     K = 1 << (K.bit_length() - 1)
     n = max(1, int(seconds / (per_particle * K)))
-    n = min(n, 8)
+    n = min(n, 200)
     t0 = time.perf_counter()
     for s in range(n):
         CO.sweep(g, Q, pi, lam, lam, K, s, jc=jc)
@@ -99,27 +101,42 @@ def main():
     ndev = _ffi.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
-    ctx = _ffi.Context(K_global, N, S, device=local_rank % ndev)
-    ctx.set_leaves(g)
-    ctx.set_model(Q, pi, lam, lam, jc69_closed_form=a.jcmodel)
+    n_streams = a.streams if a.streams > 0 else (3 if world == 1 else 1)
+    if world > 1:
+        n_streams = 1                                 # one RCCL communicator per context; keep it simple when sharded
+    ctxs = []
+    for i in range(n_streams):
+        c = _ffi.Context(K_global, N, S, device=local_rank % ndev)
+        c.set_leaves(g)
+        c.set_model(Q, pi, lam, lam, jc69_closed_form=a.jcmodel)
+        ctxs.append(c)
+    ctx = ctxs[0]
     if world > 1:
         cid = exchange_comm_id(rank, world, _ffi.comm_unique_id if rank == 0 else None)
         ctx.comm_init(rank, world, cid)
 
-    for w in range(a.warmup):
-        ctx.sweep_async(a.seed + 1000 + w)
-    ctx.synchronize()
+    def run(n, seed0):
+        for s in range(n):
+            ctxs[s % n_streams].sweep_async(seed0 + s)
+        for c in ctxs:
+            c.synchronize()
+
+    run(max(a.warmup, 0), a.seed + 1000)
     ctx.comm_barrier()
     t0 = time.perf_counter()
-    for s in range(a.steps):
-        ctx.sweep_async(a.seed + s)
-    ctx.synchronize()
+    run(a.steps, a.seed)
     ctx.comm_barrier()
     dt = time.perf_counter() - t0
     dt = ctx.comm_max(dt)                            # max over ranks
-    last = ctx.sweep_fetch(arrays=False)
+    last = ctxs[(a.steps - 1) % n_streams].sweep_fetch(arrays=False)
 
-    # dominant kernel (the Felsenstein merge): average launch duration from HIP events on the ctx stream
+    # one sweep at a time on one stream (latency of a single sweep), and the dominant kernel (the
+    # Felsenstein merge): average launch duration from HIP events on the ctx stream, nothing else in flight
+    t1 = time.perf_counter()
+    for s in range(10):
+        ctx.sweep_async(a.seed + s)
+    ctx.synchronize()
+    single_ms = (time.perf_counter() - t1) / 10 * 1e3
     prof_sweeps = 3
     merge_ms, merge_n = 0.0, 0
     for s in range(prof_sweeps):
@@ -149,7 +166,9 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if a.synthetic else "primate.p alignment (real sites), untrained model parameters",
             "config": {"workload": "%s N=%d S=%d, %s, K=%d per GPU (K_total=%d), lambda=10, full sweep of %d rank events"
                                    % (wname, N, S, "JC69" if a.jcmodel else "GTR-init (jcmodel=false)", a.n_particles, K_global, N - 1),
-                       "parallelism": "particles sharded over %d GPU(s), global resampling" % world},
+                       "parallelism": "particles sharded over %d GPU(s), global resampling" % world,
+                       "sweeps_in_flight": n_streams},
+            "single_sweep_ms": single_ms,
             "log_Z": last['logZ'],
             "roofline": {"bound": "hbm", "kernel": "pk_rank_merge", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -159,7 +178,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds)
         print(json.dumps(line), flush=True)
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == '__main__':

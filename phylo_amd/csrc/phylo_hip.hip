@@ -439,7 +439,7 @@ int phylo_resample(phylo_ctx* c, const double* logw, int K, uint64_t seed, uint3
     CHK(scratch_get(c, 1, (size_t)K * 8, &dcdf));
     CHK(scratch_get(c, 2, (size_t)K * 8, &didx));
     HIPCHK(c, hipMemcpyAsync(dw, logw, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), 0, c->stream, (const double*)dw, K,
+    hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream, (const double*)dw, K,
                        (uint64_t*)dcdf, (double*)nullptr);
     CHK(launch_check(c, "pk_resample_scan"));
     hipLaunchKernelGGL(pk_resample_search, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, (const uint64_t*)dcdf, K, K, 0, seed,
@@ -458,7 +458,7 @@ int phylo_log_zsmc(phylo_ctx* c, const double* logw, int R, int K, double* out) 
     CHK(scratch_get(c, 1, (size_t)(R + 1) * 8, &dlse));
     if (R) HIPCHK(c, hipMemcpyAsync(dw, logw, (size_t)R * K * 8, hipMemcpyHostToDevice, c->stream));
     for (int r = 0; r < R; ++r) {
-        hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), 0, c->stream, (const double*)dw + (size_t)r * K, K,
+        hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream, (const double*)dw + (size_t)r * K, K,
                            (uint64_t*)nullptr, (double*)dlse + r);
         CHK(launch_check(c, "pk_resample_scan"));
     }
@@ -485,11 +485,8 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         }
     }
     int launches = 0;
-    const bool fused = (c->world == 1) && getenv("PHYLO_FUSE_TAIL");   // experiment: last merge workgroup runs the scan
-    const bool nt = getenv("PHYLO_NT_STORE") != nullptr;
     const size_t lds = pk_book_lds_bytes(N);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_counter, 0, (((size_t)N + 3) & ~(size_t)3) * sizeof(unsigned int), c->stream));
     hipLaunchKernelGGL(pk_sweep_draws, dim3(cdiv(2L * R * Kl, 64)), dim3(64), 0, c->stream, c->d_Q, c->d_lam_l, c->d_lam_r,
                        c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat);
     CHK(launch_check(c, "pk_sweep_draws"));
@@ -502,11 +499,11 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         const int cur = r & 1, nxt = cur ^ 1;
         pk_rank_args b{};
         b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
-        b.seed = seed; b.flags = flags; b.fuse_tail = fused ? 1 : 0;
+        b.seed = seed; b.flags = flags;
         b.roots_old = c->d_roots[cur]; b.cnt_old = c->d_cnt[cur];
         b.roots_new = c->d_roots[nxt]; b.cnt_new = c->d_cnt[nxt];
         b.rootll_old = c->d_rootll[cur]; b.rootll_new = c->d_rootll[nxt];
-        b.cdf = c->d_cdf[cur]; b.cdf_next = (r + 1 < R) ? c->d_cdf[nxt] : nullptr;
+        b.cdf = c->d_cdf[cur];
         b.ll_prev = r > 0 ? c->d_ll + (size_t)(r - 1) * K : nullptr;
         b.nodell = c->d_nodell;
         b.ldf = c->d_ldf; b.ldf_n = N;
@@ -519,22 +516,19 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         b.pi = c->d_pi;
         b.logw_r = c->d_logw + (size_t)r * K;
         b.ll_r = c->d_ll + (size_t)r * K;
-        b.lse_r = c->d_lse + r;
         b.merges = c->d_merges; b.ancestors = c->d_anc;
-        b.counter = c->d_counter + r;
         b.child = c->d_child; b.aux = c->d_aux;
         hipLaunchKernelGGL(pk_rank_book, dim3(K), dim3(64), lds, c->stream, b);
         CHK(launch_check(c, "pk_rank_book"));
         if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r], c->stream));
-        if (nt) hipLaunchKernelGGL(pk_rank_merge<true>, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
-        else hipLaunchKernelGGL(pk_rank_merge<false>, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
+        hipLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
         CHK(launch_check(c, "pk_rank_merge"));
         if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r + 1], c->stream));
         launches += 2;
-        if (!fused) {
+        {
             CHK(phylo_comm_gather_rank(c->comm, c->d_logw + (size_t)r * K, c->d_ll + (size_t)r * K,
                                        c->d_nodell + N + (size_t)r * K, K, c->stream, &c->err));
-            hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), 0, c->stream,
+            hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream,
                                (const double*)(c->d_logw + (size_t)r * K), K, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
                                c->d_lse + r);
             CHK(launch_check(c, "pk_resample_scan"));

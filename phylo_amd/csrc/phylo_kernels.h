@@ -249,8 +249,10 @@ __device__ __forceinline__ void pk_scan_tile(const double* logw, int K, int base
         if (base + (int)threadIdx.x + PK_COLS * j >= K) v[j] = pm_nan();
 }
 
+// `stage`: K-element scratch for the integer weights between the two passes: LDS when it fits, else cdf[].
 __device__ __forceinline__ void pk_scan_block(const double* logw, int K, uint64_t* __restrict__ cdf,
-                                              double* __restrict__ lse_out, pk_scan_lds* sh) {
+                                              double* __restrict__ lse_out, pk_scan_lds* sh,
+                                              unsigned long long* stage) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool one_tile = K <= 8 * PK_COLS;
     double v[8];
@@ -285,7 +287,7 @@ __device__ __forceinline__ void pk_scan_block(const double* logw, int K, uint64_
             if (k < K) {
                 const double w = all_bad ? 1.0 : (pm_isnan(v[j]) ? 0.0 : pm_exp(v[j] - m));
                 col = col + w;
-                if (cdf) cdf[k] = all_bad ? 1ull : (uint64_t)(w * PM_CDF_SCALE);
+                if (cdf) stage[k] = all_bad ? 1ull : (unsigned long long)(w * PM_CDF_SCALE);
             }
         }
     }
@@ -293,7 +295,7 @@ __device__ __forceinline__ void pk_scan_block(const double* logw, int K, uint64_
     for (int off = 1; off < 64; off <<= 1) col = col + __shfl_xor(col, off, 64);
     __syncthreads();
     if (lane == 0) sh->d4[wv] = col;
-    __syncthreads();                                   // also orders the cdf[] staging stores (workgroup scope)
+    __syncthreads();                                   // also orders the staging stores (workgroup scope)
     if (tid == 0 && lse_out) {
         const double sum = ((sh->d4[0] + sh->d4[1]) + sh->d4[2]) + sh->d4[3];
         const double mm = all_bad ? 0.0 : m;
@@ -307,12 +309,12 @@ __device__ __forceinline__ void pk_scan_block(const double* logw, int K, uint64_
         const int lo = base + 8 * tid;
         unsigned long long e[8];
         if (lo + 8 <= K) {
-            const ulonglong2* q = reinterpret_cast<const ulonglong2*>(cdf + lo);
+            const ulonglong2* q = reinterpret_cast<const ulonglong2*>(stage + lo);
             const ulonglong2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             e[0] = q0.x; e[1] = q0.y; e[2] = q1.x; e[3] = q1.y; e[4] = q2.x; e[5] = q2.y; e[6] = q3.x; e[7] = q3.y;
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) e[j] = (lo + j < K) ? cdf[lo + j] : 0ull;
+            for (int j = 0; j < 8; ++j) e[j] = (lo + j < K) ? stage[lo + j] : 0ull;
         }
 #pragma unroll
         for (int j = 1; j < 8; ++j) e[j] += e[j - 1];
@@ -343,10 +345,17 @@ __device__ __forceinline__ void pk_scan_block(const double* logw, int K, uint64_
     }
 }
 
+#define PK_SCAN_LDS_MAX_K 8192
 __global__ __launch_bounds__(PK_COLS) void pk_resample_scan(const double* logw, int K, uint64_t* __restrict__ cdf,
                                                              double* __restrict__ lse_out) {
-    __shared__ pk_scan_lds sh;
-    pk_scan_block(logw, K, cdf, lse_out, &sh);
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // [pk_scan_lds][K x u64 when K fits]
+    pk_scan_lds* sh = reinterpret_cast<pk_scan_lds*>(smem);
+    unsigned long long* stage = (K <= PK_SCAN_LDS_MAX_K) ? reinterpret_cast<unsigned long long*>(smem + sizeof(pk_scan_lds))
+                                                         : reinterpret_cast<unsigned long long*>(cdf);
+    pk_scan_block(logw, K, cdf, lse_out, sh, stage);
+}
+__host__ inline size_t pk_scan_lds_bytes(int K) {
+    return sizeof(pk_scan_lds) + (K <= PK_SCAN_LDS_MAX_K ? (size_t)K * 8 : 0);
 }
 
 __device__ __forceinline__ int pk_cdf_search(const uint64_t* __restrict__ cdf, int K, uint64_t thr) {
@@ -421,12 +430,10 @@ struct pk_rank_args {
     int r, n, N, S, K /*global*/, Kloc, k0;
     uint64_t seed;
     uint32_t flags;
-    int fuse_tail;                                        // 1: last workgroup runs the next rank's scan
     const int32_t* roots_old; const int32_t* cnt_old;     // [K][N]
     int32_t* roots_new; int32_t* cnt_new;                 // [K][N]
     const double* rootll_old; double* rootll_new;         // [K][N]: sum_s log(pi . x[s]) of the root in each slot
     const uint64_t* cdf;                                  // [K] (r > 0): scan of log w_{r-1}
-    uint64_t* cdf_next;                                   // [K]: written by the fused tail
     const double* ll_prev;                                // ll[r-1][K] (r > 0)
     double* nodell;                                       // per node id
     const double* ldf; int ldf_n;                         // log (2 max(c,2) - 3)!! by leaf count
@@ -437,12 +444,10 @@ struct pk_rank_args {
     const double* Pmat;                                   // [Kloc][32] of this rank
     const double* pi;
     double* logw_r; double* ll_r;                         // [K] rows (global columns)
-    double* lse_r;                                        // log-normaliser of THIS rank's weights (fused tail)
     int32_t* merges;                                      // [R][Kloc][2]
     int64_t* ancestors;                                   // [R-1][Kloc]
     int32_t* child;                                       // [Kloc][2]: node ids merged at this rank event
     double* aux;                                          // [Kloc][PK_AUX]: weight terms for the merge epilogue
-    unsigned int* counter;                                // arrival counter of this rank event (zeroed per sweep)
 };
 
 // LDS carve of the bookkeeping prologue (arrays of length N rounded up to a multiple of 4)
@@ -633,42 +638,99 @@ __global__ __launch_bounds__(64) void pk_rank_book(const pk_rank_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The Felsenstein merge of one rank event, one workgroup (256 threads) per local particle:
-//   body      k2: the new node's partial likelihoods, out[s,:] = (L[s,:] P_l) * (R[s,:] P_r)
-//             k3: sum_s log(pi . out[s,:]) in the canonical order
-//   epilogue  k8: log_likelihood_r and log w_r (vcsmc.py:376-392)
-//   tail      the workgroup that finishes last scans the K weights for the next rank's resampling (k5)
+// The Felsenstein merge of one rank event, one workgroup (256 threads) per local particle.
+//   k2: the new node's partial likelihoods, out[s,:] = (L[s,:] P_l) * (R[s,:] P_r)      (vcsmc.py:185-187)
+//   k3: sum_s log(pi . out[s,:]) in the canonical order                                  (vcsmc.py:240-242)
+//   k8: log_likelihood_r and log w_r                                                     (vcsmc.py:376-392)
+// Half-row form: a lane PAIR owns a site.  Lane parity h loads the 16 bytes holding states 2h, 2h+1 of each
+// child (so a wave reads 1 KiB contiguous per instruction from the [K x S x 4] tensor), completes the rows
+// with DPP quad_perm moves, produces output states 2h, 2h+1 and stores its 16 bytes (non-temporal: only the
+// few particles that survive the next resampling ever read the node again).  Per 256-site step a pair takes
+// two sites, p + 256 q (-> canonical column p, finished on the even lane) and p + 128 + 256 q (-> column
+// p + 128, odd lane), so every lane runs exactly one log per step.  Arithmetic per output state is the same
+// fma chain as pk_merge_site: results are bit-identical to the row-per-thread form.
 //   algorithmic traffic: 2 x 32 B read + 32 B written per (particle, site) = 96 B / unit.
 // ------------------------------------------------------------------------------------------------
-template <bool NT>
-__global__ __launch_bounds__(PK_COLS, 6) void pk_rank_merge(const pk_rank_args a) {
-    __shared__ pk_scan_lds scan_sh;
-    __shared__ int is_last;
-    const int k = blockIdx.x, kg = a.k0 + k;
-    const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
+__device__ __forceinline__ double pk_dpp_even(double v) {   // the value held by the even lane of my pair
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xA0, 0xF, 0xF, true);       // quad_perm [0,0,2,2]
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xA0, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pk_dpp_odd(double v) {    // the value held by the odd lane of my pair
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xF5, 0xF, 0xF, true);       // quad_perm [1,1,3,3]
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xF5, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int id) {
     const size_t node_sz = (size_t)a.S * 4;
     // a child is a leaf (id < N) or a node of the local pool: id = N + rho*K + kappa
-    const double* Lp = cl < a.N ? a.leaves + (size_t)cl * node_sz
-                                : a.pool + ((size_t)((cl - a.N) / a.K) * a.Kloc + ((cl - a.N) % a.K - a.k0)) * node_sz;
-    const double* Rp = cr < a.N ? a.leaves + (size_t)cr * node_sz
-                                : a.pool + ((size_t)((cr - a.N) / a.K) * a.Kloc + ((cr - a.N) % a.K - a.k0)) * node_sz;
-    double* out = a.pool + ((size_t)a.r * a.Kloc + k) * node_sz;
-    double Pl[16], Pr[16];
-    const double* P = a.Pmat + (size_t)k * 32;
+    return id < a.N ? a.leaves + (size_t)id * node_sz
+                    : a.pool + ((size_t)((id - a.N) / a.K) * a.Kloc + ((id - a.N) % a.K - a.k0)) * node_sz;
+}
+
+__global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a) {
+    __shared__ double cols[PK_COLS];
+    __shared__ double sh4[4];
+    const int k = blockIdx.x, kg = a.k0 + k, tid = threadIdx.x, p = tid >> 1, h = tid & 1;
+    const double* Lp = pk_node_ptr(a, a.child[k * 2]) + 2 * h;
+    const double* Rp = pk_node_ptr(a, a.child[k * 2 + 1]) + 2 * h;
+    double* out = a.pool + ((size_t)a.r * a.Kloc + k) * (size_t)a.S * 4 + 2 * h;
+    const double* P = a.Pmat + (size_t)k * 32 + 2 * h;
+    double Plc[4][2], Prc[4][2];                    // my two columns (states 2h, 2h+1) of P_l and P_r
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { Pl[j] = P[j]; Pr[j] = P[16 + j]; }
-    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
-    double col = 0.0;
-    for (int s = threadIdx.x; s < a.S; s += PK_COLS) {
-        double Lv[4], Rv[4], o[4];
-        pk_load4(Lp + (size_t)s * 4, Lv);
-        pk_load4(Rp + (size_t)s * 4, Rv);
-        pk_merge_site(Lv, Rv, Pl, Pr, o);
-        if (NT) pk_store4_nt(out + (size_t)s * 4, o); else pk_store4(out + (size_t)s * 4, o);
-        col = col + pm_log(pk_site_lik(pi, o));
+    for (int i = 0; i < 4; ++i) {
+        const pk_d2 x = *reinterpret_cast<const pk_d2*>(P + i * 4);
+        const pk_d2 y = *reinterpret_cast<const pk_d2*>(P + 16 + i * 4);
+        Plc[i][0] = x.x; Plc[i][1] = x.y; Prc[i][0] = y.x; Prc[i][1] = y.y;
     }
-    const double tot = pk_block_canon_sum(col, scan_sh.d4);
-    if (threadIdx.x == 0) {
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    const int S = a.S;
+    double col = 0.0;
+    pk_d2 nla = {0, 0}, nra = {0, 0}, nlb = {0, 0}, nrb = {0, 0};     // software pipeline: next step's rows
+    if (p < S) { nla = *reinterpret_cast<const pk_d2*>(Lp + (size_t)p * 4); nra = *reinterpret_cast<const pk_d2*>(Rp + (size_t)p * 4); }
+    if (p + 128 < S) { nlb = *reinterpret_cast<const pk_d2*>(Lp + (size_t)(p + 128) * 4); nrb = *reinterpret_cast<const pk_d2*>(Rp + (size_t)(p + 128) * 4); }
+    const int nq = (S + 255) >> 8;
+    for (int q = 0; q < nq; ++q) {
+        const int sa = p + 256 * q, sb = sa + 128;
+        const bool va = sa < S, vb = sb < S;
+        const pk_d2 la = nla, ra = nra, lb = nlb, rb = nrb;
+        if (sa + 256 < S) { nla = *reinterpret_cast<const pk_d2*>(Lp + (size_t)(sa + 256) * 4); nra = *reinterpret_cast<const pk_d2*>(Rp + (size_t)(sa + 256) * 4); }
+        if (sb + 256 < S) { nlb = *reinterpret_cast<const pk_d2*>(Lp + (size_t)(sb + 256) * 4); nrb = *reinterpret_cast<const pk_d2*>(Rp + (size_t)(sb + 256) * 4); }
+        double lik[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const pk_d2 l2 = t ? lb : la, r2 = t ? rb : ra;
+            const double L[4] = {pk_dpp_even(l2.x), pk_dpp_even(l2.y), pk_dpp_odd(l2.x), pk_dpp_odd(l2.y)};
+            const double R[4] = {pk_dpp_even(r2.x), pk_dpp_even(r2.y), pk_dpp_odd(r2.x), pk_dpp_odd(r2.y)};
+            double o[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                double lp = L[0] * Plc[0][c];
+                lp = pm_fma(L[1], Plc[1][c], lp);
+                lp = pm_fma(L[2], Plc[2][c], lp);
+                lp = pm_fma(L[3], Plc[3][c], lp);
+                double rp = R[0] * Prc[0][c];
+                rp = pm_fma(R[1], Prc[1][c], rp);
+                rp = pm_fma(R[2], Prc[2][c], rp);
+                rp = pm_fma(R[3], Prc[3][c], rp);
+                o[c] = lp * rp;
+            }
+            if (t ? vb : va) {
+                const pk_d2 ov = {o[0], o[1]};
+                __builtin_nontemporal_store(ov, reinterpret_cast<pk_d2*>(out + (size_t)(t ? sb : sa) * 4));
+            }
+            const double f[4] = {pk_dpp_even(o[0]), pk_dpp_even(o[1]), pk_dpp_odd(o[0]), pk_dpp_odd(o[1])};
+            lik[t] = pk_site_lik(pi, f);
+        }
+        if (h ? vb : va) col = col + pm_log(h ? lik[1] : lik[0]);
+    }
+    cols[p + 128 * h] = col;                        // lane (p, h) owns canonical column p + 128 h
+    __syncthreads();
+    const double tot = pk_block_canon_sum(cols[tid], sh4);
+    if (tid == 0) {
         const double* ax = a.aux + (size_t)k * PK_AUX;
         const double fl = ax[AUX_SUM_REM] + tot;
         const double ll = ((fl + ax[AUX_FPRIOR]) + ax[AUX_LPRIOR]) + ax[AUX_RPRIOR];
@@ -676,17 +738,8 @@ __global__ __launch_bounds__(PK_COLS, 6) void pk_rank_merge(const pk_rank_args a
         a.nodell[a.N + a.r * a.K + kg] = tot;
         a.rootll_new[(size_t)kg * a.N + (a.n - 2)] = tot;
         a.ll_r[kg] = ll;
-        pk_st_agent(a.logw_r + kg, lw);                 // write-through: read by the tail of THIS launch
-        int last = 0;
-        if (a.fuse_tail) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned int ticket = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last = (ticket == (unsigned int)(a.Kloc - 1)) ? 1 : 0;
-        }
-        is_last = last;
+        a.logw_r[kg] = lw;
     }
-    __syncthreads();
-    if (is_last) pk_scan_block(a.logw_r, a.K, a.cdf_next, a.lse_r, &scan_sh);
 }
 
 // arithmetic probe

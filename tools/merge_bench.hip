@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../phylo_amd/csrc/phylo_kernels.h"
@@ -113,6 +114,148 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void k_loadall(const Args a) {
     }
     const double tot = pk_block_canon_sum(col, sh4);
     if (threadIdx.x == 0) a.outll[k] = tot;
+}
+
+// ---- half-row form: a lane PAIR owns a site; each lane loads/stores 16 contiguous bytes (states 2h, 2h+1),
+// rows are completed through DPP quad_perm moves, each lane produces 2 of the 4 output states.
+__device__ __forceinline__ double hb_dpp_even(double v) {   // value held by the even lane of my pair
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xA0, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xA0, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double hb_dpp_odd(double v) {    // value held by the odd lane of my pair
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xF5, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xF5, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int WAVES_PER_EU, bool NT>
+__global__ __launch_bounds__(256, WAVES_PER_EU) void k_half(const Args a) {
+    __shared__ double cols[256];
+    __shared__ double sh4[4];
+    const int k = blockIdx.x, tid = threadIdx.x, p = tid >> 1, h = tid & 1;
+    const double* Lp = child_ptr(a, a.child[k * 2]);
+    const double* Rp = child_ptr(a, a.child[k * 2 + 1]);
+    double* out = a.pool + ((size_t)a.r * a.K + k) * a.S * 4;
+    const double* P = a.Pmat + (size_t)k * 32;
+    double Plc[4][2], Prc[4][2];                    // my two columns (states 2h, 2h+1) of P_l and P_r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const pk_d2 x = *reinterpret_cast<const pk_d2*>(P + i * 4 + 2 * h);
+        const pk_d2 y = *reinterpret_cast<const pk_d2*>(P + 16 + i * 4 + 2 * h);
+        Plc[i][0] = x.x; Plc[i][1] = x.y; Prc[i][0] = y.x; Prc[i][1] = y.y;
+    }
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    double col = 0.0;
+    const int nq = (a.S + 255) >> 8;
+    for (int q = 0; q < nq; ++q) {
+        const int sa = p + 256 * q, sb = sa + 128;
+        const bool va = sa < a.S, vb = sb < a.S;
+        pk_d2 la = {0, 0}, ra = {0, 0}, lb = {0, 0}, rb = {0, 0};
+        if (va) { la = *reinterpret_cast<const pk_d2*>(Lp + (size_t)sa * 4 + 2 * h); ra = *reinterpret_cast<const pk_d2*>(Rp + (size_t)sa * 4 + 2 * h); }
+        if (vb) { lb = *reinterpret_cast<const pk_d2*>(Lp + (size_t)sb * 4 + 2 * h); rb = *reinterpret_cast<const pk_d2*>(Rp + (size_t)sb * 4 + 2 * h); }
+        double lik[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const pk_d2 l2 = t ? lb : la, r2 = t ? rb : ra;
+            const double L[4] = {hb_dpp_even(l2.x), hb_dpp_even(l2.y), hb_dpp_odd(l2.x), hb_dpp_odd(l2.y)};
+            const double R[4] = {hb_dpp_even(r2.x), hb_dpp_even(r2.y), hb_dpp_odd(r2.x), hb_dpp_odd(r2.y)};
+            double o[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                double lp = L[0] * Plc[0][c];
+                lp = pm_fma(L[1], Plc[1][c], lp);
+                lp = pm_fma(L[2], Plc[2][c], lp);
+                lp = pm_fma(L[3], Plc[3][c], lp);
+                double rp = R[0] * Prc[0][c];
+                rp = pm_fma(R[1], Prc[1][c], rp);
+                rp = pm_fma(R[2], Prc[2][c], rp);
+                rp = pm_fma(R[3], Prc[3][c], rp);
+                o[c] = lp * rp;
+            }
+            const int s = t ? sb : sa;
+            if (t ? vb : va) {
+                pk_d2 ov = {o[0], o[1]};
+                if (NT) __builtin_nontemporal_store(ov, reinterpret_cast<pk_d2*>(out + (size_t)s * 4 + 2 * h));
+                else *reinterpret_cast<pk_d2*>(out + (size_t)s * 4 + 2 * h) = ov;
+            }
+            const double f[4] = {hb_dpp_even(o[0]), hb_dpp_even(o[1]), hb_dpp_odd(o[0]), hb_dpp_odd(o[1])};
+            lik[t] = pk_site_lik(pi, f);
+        }
+        const bool mine = h ? vb : va;                 // even lane: site a -> column p; odd lane: site b -> column p+128
+        if (mine) col = col + pm_log(h ? lik[1] : lik[0]);
+    }
+    cols[p + 128 * h] = col;
+    __syncthreads();
+    const double tot = pk_block_canon_sum(cols[tid], sh4);
+    if (tid == 0) a.outll[k] = tot;
+}
+
+template <int WAVES_PER_EU, bool NT>
+__global__ __launch_bounds__(256, WAVES_PER_EU) void k_half_pf(const Args a) {
+    __shared__ double cols[256];
+    __shared__ double sh4[4];
+    const int k = blockIdx.x, tid = threadIdx.x, p = tid >> 1, h = tid & 1;
+    const double* Lp = child_ptr(a, a.child[k * 2]);
+    const double* Rp = child_ptr(a, a.child[k * 2 + 1]);
+    double* out = a.pool + ((size_t)a.r * a.K + k) * a.S * 4;
+    const double* P = a.Pmat + (size_t)k * 32;
+    double Plc[4][2], Prc[4][2];                    // my two columns (states 2h, 2h+1) of P_l and P_r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const pk_d2 x = *reinterpret_cast<const pk_d2*>(P + i * 4 + 2 * h);
+        const pk_d2 y = *reinterpret_cast<const pk_d2*>(P + 16 + i * 4 + 2 * h);
+        Plc[i][0] = x.x; Plc[i][1] = x.y; Prc[i][0] = y.x; Prc[i][1] = y.y;
+    }
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    double col = 0.0;
+    const int nq = (a.S + 255) >> 8;
+    pk_d2 nla = {0, 0}, nra = {0, 0}, nlb = {0, 0}, nrb = {0, 0};
+    if (p < a.S) { nla = *reinterpret_cast<const pk_d2*>(Lp + (size_t)p * 4 + 2 * h); nra = *reinterpret_cast<const pk_d2*>(Rp + (size_t)p * 4 + 2 * h); }
+    if (p + 128 < a.S) { nlb = *reinterpret_cast<const pk_d2*>(Lp + (size_t)(p + 128) * 4 + 2 * h); nrb = *reinterpret_cast<const pk_d2*>(Rp + (size_t)(p + 128) * 4 + 2 * h); }
+    for (int q = 0; q < nq; ++q) {
+        const int sa = p + 256 * q, sb = sa + 128;
+        const bool va = sa < a.S, vb = sb < a.S;
+        const pk_d2 la = nla, ra = nra, lb = nlb, rb = nrb;
+        if (sa + 256 < a.S) { nla = *reinterpret_cast<const pk_d2*>(Lp + (size_t)(sa + 256) * 4 + 2 * h); nra = *reinterpret_cast<const pk_d2*>(Rp + (size_t)(sa + 256) * 4 + 2 * h); }
+        if (sb + 256 < a.S) { nlb = *reinterpret_cast<const pk_d2*>(Lp + (size_t)(sb + 256) * 4 + 2 * h); nrb = *reinterpret_cast<const pk_d2*>(Rp + (size_t)(sb + 256) * 4 + 2 * h); }
+        double lik[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const pk_d2 l2 = t ? lb : la, r2 = t ? rb : ra;
+            const double L[4] = {hb_dpp_even(l2.x), hb_dpp_even(l2.y), hb_dpp_odd(l2.x), hb_dpp_odd(l2.y)};
+            const double R[4] = {hb_dpp_even(r2.x), hb_dpp_even(r2.y), hb_dpp_odd(r2.x), hb_dpp_odd(r2.y)};
+            double o[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                double lp = L[0] * Plc[0][c];
+                lp = pm_fma(L[1], Plc[1][c], lp);
+                lp = pm_fma(L[2], Plc[2][c], lp);
+                lp = pm_fma(L[3], Plc[3][c], lp);
+                double rp = R[0] * Prc[0][c];
+                rp = pm_fma(R[1], Prc[1][c], rp);
+                rp = pm_fma(R[2], Prc[2][c], rp);
+                rp = pm_fma(R[3], Prc[3][c], rp);
+                o[c] = lp * rp;
+            }
+            const int s = t ? sb : sa;
+            if (t ? vb : va) {
+                pk_d2 ov = {o[0], o[1]};
+                if (NT) __builtin_nontemporal_store(ov, reinterpret_cast<pk_d2*>(out + (size_t)s * 4 + 2 * h));
+                else *reinterpret_cast<pk_d2*>(out + (size_t)s * 4 + 2 * h) = ov;
+            }
+            const double f[4] = {hb_dpp_even(o[0]), hb_dpp_even(o[1]), hb_dpp_odd(o[0]), hb_dpp_odd(o[1])};
+            lik[t] = pk_site_lik(pi, f);
+        }
+        const bool mine = h ? vb : va;                 // even lane: site a -> column p; odd lane: site b -> column p+128
+        if (mine) col = col + pm_log(h ? lik[1] : lik[0]);
+    }
+    cols[p + 128 * h] = col;
+    __syncthreads();
+    const double tot = pk_block_canon_sum(cols[tid], sh4);
+    if (tid == 0) a.outll[k] = tot;
 }
 
 // pure store of the output slab (write ceiling at this grid shape)
@@ -237,6 +380,28 @@ int main(int argc, char** argv) {
             RUN("loadall nt w4", (k_loadall<4, true>));
             RUN("loadall nt w6", (k_loadall<6, true>));
             RUN("loadall w4", (k_loadall<4, false>));
+        }
+        RUN("half-row w6", (k_half<6, false>));
+        RUN("half-row nt w6", (k_half<6, true>));
+        RUN("half-row pf nt w6", (k_half_pf<6, true>));
+        RUN("half-row pf nt w4", (k_half_pf<4, true>));
+        RUN("half-row pf w4", (k_half_pf<4, false>));
+        RUN("half-row nt w4", (k_half<4, true>));
+        {   // bit-for-bit check of the half-row form against the base kernel on rank R-1
+            std::vector<double> o1((size_t)K), o2((size_t)K), n1((size_t)K * S * 4), n2((size_t)K * S * 4);
+            Args b = a; b.r = R - 1; b.child = childs[R - 1];
+            hipLaunchKernelGGL((k_base<0, 6>), dim3(K), dim3(256), 0, st, b);
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(o1.data(), outll, K * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(n1.data(), pool + (size_t)(R - 1) * K * S * 4, n1.size() * 8, hipMemcpyDeviceToHost));
+            hipLaunchKernelGGL((k_half<6, true>), dim3(K), dim3(256), 0, st, b);
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(o2.data(), outll, K * 8, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(n2.data(), pool + (size_t)(R - 1) * K * S * 4, n2.size() * 8, hipMemcpyDeviceToHost));
+            size_t bad = 0, badn = 0;
+            for (int i = 0; i < K; ++i) bad += memcmp(&o1[i], &o2[i], 8) != 0;
+            for (size_t i = 0; i < n1.size(); ++i) badn += memcmp(&n1[i], &n2[i], 8) != 0;
+            printf("half-row vs base: %zu of %d sums differ, %zu of %zu partials differ\n", bad, K, badn, n1.size());
         }
         RUN("fill (store only)", (k_fill<false>));
         RUN("fill nt (store only)", (k_fill<true>));
