@@ -1,0 +1,260 @@
+"""VCSMC: the reference's class surface (vcsmc.py:103-645) over the MI355X library.
+
+Same constructor, attribute names and method names/argument meaning as the reference.  Where the reference
+builds TensorFlow graph nodes, these methods take and return NumPy arrays and run the computation on the
+GPU through the C ABI (phylo_amd/_ffi.py).  No TensorFlow, no PyTorch, no CPU fallback for the hot ops.
+
+Differences that are deliberate:
+  * randomness is the counter-based contract of DESIGN.md (`seed` attribute; the reference sets no seed);
+  * jump chains are rebuilt on the host from integer merge records, with the correct per-particle gather
+    (the reference's vcsmc.py:306-307 gathers without the row offset, fixed in vncsmc.py);
+  * train() evaluates log Z-hat per epoch; the optimiser step (vcsmc.py:488-491, 534) is not part of this
+    build, so model parameters stay at their initial values.
+"""
+from __future__ import annotations
+
+from datetime import datetime
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _ffi, model, rng
+
+
+def ncr(n, r):
+    """vcsmc.py:23-27: n choose r as product / product (true division -> float)."""
+    numer = np.prod(np.arange(n - r + 1, n + 1), dtype=np.int64) if r > 0 else 1
+    denom = np.prod(np.arange(1, r + 1), dtype=np.int64) if r > 0 else 1
+    return numer / denom
+
+
+def log_double_factorial(n):
+    """vcsmc.py:40-57: log n!! via the loop n, n-2, ... while >= 2; works on arrays."""
+    n = np.asarray(n, dtype=np.float64).copy()
+    result = np.zeros_like(n)
+    while np.count_nonzero(n >= 2):
+        result = np.where(n >= 2, result + np.log(np.where(n >= 2, n, 1.0)), result)
+        n = n - 2
+    return result
+
+
+def gather_across_2d(a, idx, a_shape_1=None, idx_shape_1=None):
+    """vcsmc.py:60-77: [a[k][idx[k]] for k]."""
+    a, idx = np.asarray(a), np.asarray(idx)
+    return a[np.arange(a.shape[0])[:, None], idx]
+
+
+def gather_across_core(a, idx, a_shape_1=None, idx_shape_1=None, A=4):
+    """vcsmc.py:80-97: per-particle row gather of a [K,N,S,A] core."""
+    a, idx = np.asarray(a), np.asarray(idx)
+    return a[np.arange(a.shape[0])[:, None], idx]
+
+
+def default_args(**kw):
+    """The reference's argparse defaults (runner.py:12-58) as a namespace."""
+    d = dict(dataset='primate_data', n_particles=10, batch_size=256, learning_rate=0.001, num_epoch=100,
+             optimizer='GradientDescentOptimizer', branch_prior=np.log(10), M=10, nested=False, jcmodel=False,
+             memory_optimization='on', seed=0, n_gpus=1)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+class VCSMC:
+    """
+    VCSMC takes as input a dictionary (datadict) with two keys:
+     taxa: a list of n strings denoting taxa
+     genome_NxSxA: a 3 tensor of genomes for the n taxa one hot encoded
+    """
+
+    def __init__(self, datadict, K, args=None, device=0):
+        self.args = args if args is not None else default_args()
+        self.taxa = datadict['taxa']
+        self.genome_NxSxA = np.asarray(datadict['genome'], dtype=np.float64)
+        self.K = K
+        self.M = self.args.M
+        self.N = len(self.genome_NxSxA)
+        self.S = len(self.genome_NxSxA[0])
+        self.A = len(self.genome_NxSxA[0, 0])
+        self.seed = int(getattr(self.args, 'seed', 0) or 0)
+        self.left_branches_param = model.branch_rates(self.N, self.args.branch_prior)    # vcsmc.py:119
+        self.right_branches_param = model.branch_rates(self.N, self.args.branch_prior)   # vcsmc.py:120
+        if not self.args.jcmodel:
+            self.y_q = model.init_y_q(self.A)                                            # vcsmc.py:122
+            self.Qmatrix = self.get_Q()
+            self.y_station = np.zeros(self.A) + 1 / self.A
+        else:
+            self.Qmatrix = model.jc_Q(self.A)                                            # vcsmc.py:126-129
+            self.y_station = np.zeros(self.A) + 1 / self.A
+        self.stationary_probs = self.get_stationary_probs()
+        self._device = device
+        self._ctx = None
+        self._sweeps = 0
+
+    # ---- device context -----------------------------------------------------------------------------
+    def _context(self):
+        if self._ctx is None:
+            ctx = _ffi.Context(self.K, self.N, self.S, self.A, device=self._device)
+            ctx.set_leaves(self.genome_NxSxA)
+            self._ctx = ctx
+        self._ctx.set_model(self.Qmatrix, self.stationary_probs, self.left_branches_param, self.right_branches_param,
+                            jc69_closed_form=bool(self.args.jcmodel))
+        return self._ctx
+
+    def close(self):
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    # ---- model (vcsmc.py:133-148) -------------------------------------------------------------------
+    def get_stationary_probs(self):
+        """ Compute stationary probabilities of the Q matrix """
+        return model.get_stationary_probs(self.y_station)
+
+    def get_Q(self):
+        """Off-diagonal terms by the softmax function, diagonal = -row sum (vcsmc.py:138-148)."""
+        return model.get_Q(self.y_q)
+
+    # ---- per-rank ops -------------------------------------------------------------------------------
+    def conditional_likelihood(self, l_data, r_data, l_branch, r_branch):
+        """vcsmc.py:150-161: (l_data @ expm(Q l_branch)) * (r_data @ expm(Q r_branch)), [S,A]."""
+        l = np.asarray(l_data, dtype=np.float64)[None]
+        r = np.asarray(r_data, dtype=np.float64)[None]
+        return self._context().cond_likelihood_K(l, r, np.array([l_branch], dtype=np.float64),
+                                                 np.array([r_branch], dtype=np.float64))[0]
+
+    def broadcast_conditional_likelihood_K(self, l_data_KxSxA, r_data_KxSxA, l_branch_samples_K, r_branch_samples_K):
+        """vcsmc.py:180-188."""
+        return self._context().cond_likelihood_K(l_data_KxSxA, r_data_KxSxA, l_branch_samples_K, r_branch_samples_K)
+
+    def compute_forest_posterior(self, data_KxXxSxA, leafnode_num_record, r=None):
+        """vcsmc.py:231-245 (r only fixes the reshape in the reference; shapes are taken from the data)."""
+        return self._context().forest_loglik(data_KxXxSxA, leafnode_num_record)
+
+    def overcounting_correct(self, leafnode_num_record):
+        """vcsmc.py:247-252."""
+        rec = np.asarray(leafnode_num_record)
+        return np.sum(rec - (rec == 1).astype(np.int32), axis=1)
+
+    def compute_log_ZSMC(self, log_weights):
+        """vcsmc.py:270-277."""
+        return self._context().log_zsmc(np.atleast_2d(log_weights))
+
+    def resample(self, core, leafnode_num_record, JC_K, log_weights, step=1):
+        """vcsmc.py:279-289: indices ~ Categorical(softmax(log_weights)), K draws; gathers core / record /
+        jump chains by them.  `step` is the rank event the draw belongs to (RNG counter)."""
+        indices = self._context().resample(log_weights, self.seed, step)
+        return (np.asarray(core)[indices], np.asarray(leafnode_num_record)[indices], np.asarray(JC_K)[indices],
+                indices)
+
+    def extend_partial_state(self, JCK, r):
+        """vcsmc.py:291-316: two root slots to coalesce per particle, the remaining slots, q = 1/C(N-r,2)
+        and the new jump-chain strings."""
+        n = self.N - r
+        q = 1 / ncr(n, 2)
+        coalesced_indices, remaining_indices = rng.pair_order(self.K, n, self.seed, r)
+        JCK = np.asarray(JCK, dtype=object)
+        keep = gather_across_2d(JCK, remaining_indices)
+        particles = gather_across_2d(JCK, coalesced_indices)
+        coalesced = np.array([a + '+' + b for a, b in particles], dtype=object)
+        return coalesced_indices, remaining_indices, q, np.concatenate([keep, coalesced[:, None]], axis=1)
+
+    def get_log_likelihood(self, log_likelihood):
+        """vcsmc.py:254-268, including its use of the LEFT rates for the right multiplier (quirk Q8)."""
+        l_exponent = self.left_branches.T * self.left_branches_param[None, :]
+        r_exponent = self.right_branches.T * self.right_branches_param[None, :]
+        l_multiplier = np.log(self.left_branches_param)[None, :]
+        r_multiplier = np.log(self.left_branches_param)[None, :]
+        left_branches_logprior = np.sum(l_multiplier - l_exponent, axis=1)
+        right_branches_logprior = np.sum(r_multiplier - r_exponent, axis=1)
+        return log_likelihood[self.N - 2] + log_double_factorial(2 * self.N - 3) - left_branches_logprior \
+            - right_branches_logprior
+
+    # ---- the sweep ----------------------------------------------------------------------------------
+    def sample_phylogenies(self, seed=None, flags=_ffi.FLAGS_DEFAULT):
+        """vcsmc.py:406-451: the N-1 rank events on the device.  Sets the reference's attributes and
+        returns the ELBO (log Z-hat)."""
+        seed = self.seed + self._sweeps if seed is None else int(seed)
+        self._sweeps += 1
+        out = self._context().sweep(seed, flags=flags, M=self.M)
+        self.log_weights = out['log_weights']            # rows 1..N-1 of the reference's tensor
+        self.log_likelihood = out['log_likelihood']
+        self.left_branches = out['left_branches']
+        self.right_branches = out['right_branches']
+        self.merges = out['merges']
+        self.ancestors = out['ancestors']
+        self.elbo = out['logZ']
+        self.cost = -self.elbo
+        self.log_likelihood_R = self.get_log_likelihood(self.log_likelihood)
+        self.stats = out['stats']
+        self._last_seed = seed
+        anc = out['ancestors']
+        self.log_likelihood_tilde = (out['log_likelihood'][self.N - 3, anc[self.N - 3]] if self.N > 2
+                                     else np.zeros(self.K) + np.log(1 / self.K))
+        self.jump_chain_tensor, self.v_minus = self._final_tables()
+        return self.elbo
+
+    def _final_tables(self):
+        """Root-table strings and v_minus after the last rank event, replayed on the host from the
+        integer records (ancestors, merges) and the pair-order contract."""
+        K, N = self.K, self.N
+        jc = np.array([list(self.taxa)] * K, dtype=object)
+        rec = np.ones((K, N), dtype=np.int64)
+        for r in range(N - 1):
+            if r > 0:
+                idx = self.ancestors[r - 1]
+                jc, rec = jc[idx], rec[idx]
+            co, rem = rng.pair_order(K, N - r, self._last_seed, r)
+            assert np.array_equal(co, self.merges[r]), "host replay of the pair pick disagrees with the device"
+            new = np.array([a + '+' + b for a, b in gather_across_2d(jc, co)], dtype=object)
+            jc = np.concatenate([gather_across_2d(jc, rem), new[:, None]], axis=1)
+            rec = np.concatenate([gather_across_2d(rec, rem), gather_across_2d(rec, co).sum(axis=1)[:, None]], axis=1)
+        return jc, self.overcounting_correct(rec)
+
+    @property
+    def jump_chains(self):
+        return self.jump_chain_tensor
+
+    def batch_slices(self, data, batch_size):
+        """vcsmc.py:453-464 (python's global RNG, like the reference)."""
+        import random
+        sites = data.shape[2]
+        sites_list = list(range(sites))
+        num_batches = sites // batch_size
+        slices = []
+        for i in range(num_batches):
+            sampled_indices = random.sample(sites_list, batch_size)
+            slices.append(sampled_indices)
+            sites_list = list(set(sites_list) - set(sampled_indices))
+        if len(sites_list) != 0:
+            slices.append(sites_list)
+        return slices
+
+    def train(self, epochs=100, batch_size=128, learning_rate=0.001, memory_optimization='on'):
+        """vcsmc.py:466-645 without the optimiser step: one full-S evaluation sweep per epoch (the sweep the
+        reference reports, vcsmc.py:538-551), same printed lines.  Returns the per-epoch ELBOs."""
+        self.lr = learning_rate
+        print('================= Dataset shape: KxNxSxA =================')
+        print((self.K, self.N, self.S, self.A))
+        print('==========================================================')
+        initial = self.sample_phylogenies()
+        print('===================\nInitial evaluation of ELBO:', round(initial, 3))
+        print('Initial jump chain:')
+        print(self.jump_chains[0])
+        print('===================')
+        print('Training begins --')
+        elbos = []
+        for i in range(epochs):
+            bt = datetime.now()
+            elbo = self.sample_phylogenies()
+            print('Epoch', i + 1)
+            print('ELBO\n', round(elbo, 3))
+            print('Stationary probabilities\n', self.stationary_probs)
+            print('Q-matrix\n', self.Qmatrix)
+            print('LB param:\n', self.left_branches_param)
+            print('RB param:\n', self.right_branches_param)
+            elbos.append(elbo)
+            at = datetime.now()
+            print('Time spent\n', at - bt, '\n-----------------------------------------')
+        print("Done training.")
+        self.elbos = np.asarray(elbos)
+        return self.elbos
