@@ -1,0 +1,86 @@
+"""Sharded restatement of the sweep (TEST INFRASTRUCTURE): the multi-GPU protocol of DESIGN.md in NumPy.
+
+Each rank owns the particles [rank*K/G, (rank+1)*K/G).  Integer state (root tables, leaf counts) is
+REPLICATED and advanced for all K particles on every rank from the shared counter-based draws; float state
+(node partial likelihoods) exists only on the owner.  Per rank event the ranks all-gather three K-vectors
+(log-weights, log-likelihoods, node log-likelihoods); a child node owned by another rank is fetched from its
+owner when (and only when) it is merged.  `comm` needs all_gather(np.ndarray) -> list of arrays and
+fetch_node(owner, key) (tests wire these to torch.distributed gloo).  The result must equal cpu_ref.sweep.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import cpu_ref as O
+
+
+def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, flags=O.QUIRK_Q1_RAW_Q):
+    N, S, A = genome.shape
+    Kl = K // world
+    k0 = rank * Kl
+    local = slice(k0, k0 + Kl)
+    roots = np.tile(np.arange(N), (K, 1))                    # node ids; leaves 0..N-1, node (r, k) = N + r*K + k
+    cnt = np.ones((K, N), dtype=np.int64)
+    leaf_ll = np.sum(np.log(np.matmul(genome, pi_1xA[0])), axis=1)
+    rootll = np.tile(leaf_ll, (K, 1))
+    pool = {}                                                # (r, k) -> [S,4] for LOCAL k only
+    fetched = 0
+    log_weights, log_lik = np.zeros((N - 1, K)), np.zeros((N - 1, K))
+    bls, brs = np.zeros((N - 1, Kl)), np.zeros((N - 1, Kl))
+    ancestors = np.zeros((max(N - 2, 0), K), dtype=np.int64)
+    ll_tilde = np.zeros(K) + np.log(1.0 / K)
+
+    def node_data(node_id):
+        nonlocal fetched
+        if node_id < N:
+            return genome[node_id]
+        r_, k_ = divmod(node_id - N, K)
+        owner = k_ // Kl
+        if owner == rank:
+            return pool[(r_, k_)]
+        fetched += 1
+        return comm.fetch_node(owner, (r_, k_))              # read in place over xGMI on the GPU path
+
+    for r in range(N - 1):
+        n = N - r
+        if r > 0:
+            idx = O.resample_indices(log_weights[r - 1], seed, r)        # identical on every rank
+            roots, cnt, rootll = roots[idx], cnt[idx], rootll[idx]
+            ll_tilde = log_lik[r - 1, idx]
+            ancestors[r - 1] = idx
+        co, rem, q = O.extend_partial_state(K, n, seed, r)               # replicated integer bookkeeping
+        ar = np.arange(K)
+        cl, cr = roots[ar, co[:, 0]], roots[ar, co[:, 1]]
+        new_cnt = cnt[ar, co[:, 0]] + cnt[ar, co[:, 1]]
+        roots_rem, cnt_rem, ll_rem = roots[ar[:, None], rem], cnt[ar[:, None], rem], rootll[ar[:, None], rem]
+        bl, br = O.branch_samples(Kl, lam_l[r], lam_r[r], seed, r, k0=k0)
+        bls[r], brs[r] = bl, br
+        # serve the nodes other ranks need from me, then merge my own particles
+        comm.serve_begin(pool)
+        L = np.stack([node_data(int(c)) for c in cl[local]])
+        R = np.stack([node_data(int(c)) for c in cr[local]])
+        comm.serve_end()
+        new = O.broadcast_conditional_likelihood_K(Q, L, R, bl, br)
+        node_ll = np.sum(np.log(np.matmul(new, pi_1xA[0])), axis=1)
+        for j in range(Kl):
+            pool[(r, k0 + j)] = new[j]
+        cnt_new = np.concatenate([cnt_rem, new_cnt[:, None]], axis=1)
+        fprior = np.sum(-O.log_double_factorial(2 * np.maximum(cnt_new, 2) - 3), axis=1)
+        ll_r = ll_rem[local].sum(axis=1) + node_ll + fprior[local]
+        ll_r = ll_r + np.sum(-lam_l[r] * bls[:r + 1] + np.log(lam_l[r]), axis=0) \
+                    + np.sum(-lam_r[r] * brs[:r + 1] + np.log(lam_r[r]), axis=0)
+        v_minus = O.overcounting_correct(cnt_new)[local]
+        qterm = q if (flags & O.QUIRK_Q1_RAW_Q) else np.log(q)
+        lw = ll_r - ll_tilde[local] - (np.log(lam_l[r]) - lam_l[r] * bl + np.log(lam_r[r]) - lam_r[r] * br) \
+            + np.log(v_minus.astype(np.float64)) - qterm
+        # the one collective of the rank event: three K-vectors
+        g = comm.all_gather(np.stack([lw, ll_r, node_ll]))
+        full = np.concatenate(g, axis=1)
+        log_weights[r], log_lik[r], node_ll_all = full[0], full[1], full[2]
+        new_ids = N + r * K + np.arange(K)
+        roots = np.concatenate([roots_rem, new_ids[:, None]], axis=1)
+        cnt = cnt_new
+        rootll = np.concatenate([ll_rem, node_ll_all[:, None]], axis=1)
+    logZ = O.compute_log_ZSMC(np.concatenate([np.zeros((1, K)), log_weights]))
+    return {'log_weights': log_weights, 'log_likelihood': log_lik, 'ancestors': ancestors, 'logZ': logZ,
+            'remote_fetches': fetched}

@@ -54,7 +54,8 @@ struct phylo_ctx {
     int32_t* d_merges = nullptr;         // [(N-1)][Kloc][2]
     int64_t* d_anc = nullptr;            // [(N-2)][Kloc]
     uint64_t* d_cdf[2] = {nullptr, nullptr};   // [K], double-buffered across rank events
-    unsigned int* d_counter = nullptr;   // [N] arrival counters, one per rank event
+    unsigned int* d_counter = nullptr;   // (unused)
+    const double** d_pool_ptrs = nullptr; // [world] pool base of every rank (peer mappings)
     phylo_stats stats{};
     uint32_t last_flags = 0;
     int n_merge_events = 0;
@@ -135,7 +136,7 @@ int launch_check(phylo_ctx* ctx, const char* what) {
 void free_sweep_state(phylo_ctx* c) {
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
                     c->d_roots[0], c->d_roots[1], c->d_cnt[0], c->d_cnt[1], c->d_child, c->d_merges, c->d_anc,
-                    c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1]};
+                    c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1], (void*)c->d_pool_ptrs};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_pool = c->d_nodell = c->d_bl = c->d_br = c->d_Pmat = c->d_logw = c->d_ll = c->d_aux = c->d_lse = nullptr;
@@ -144,6 +145,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_cdf[0] = c->d_cdf[1] = nullptr;
     c->d_counter = nullptr;
     c->d_rootll[0] = c->d_rootll[1] = nullptr;
+    c->d_pool_ptrs = nullptr;
 }
 
 int alloc_sweep_state(phylo_ctx* c) {
@@ -169,6 +171,11 @@ int alloc_sweep_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_cdf[0], K));
     CHK(dalloc(c, &c->d_cdf[1], K));
     CHK(dalloc(c, &c->d_counter, ((size_t)N + 3) & ~(size_t)3));
+    CHK(dalloc(c, &c->d_pool_ptrs, (size_t)c->world));
+    std::vector<void*> ptrs;
+    int rc = phylo_comm_map_pools(c->comm, c->d_pool, &ptrs, c->stream, &c->err);
+    if (rc != PHYLO_OK) return rc;
+    HIPCHK(c, hipMemcpy((void*)c->d_pool_ptrs, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice));
     return PHYLO_OK;
 }
 
@@ -511,7 +518,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         b.lam_l = c->h_lam_l[r]; b.lam_r = c->h_lam_r[r];
         b.loglam_l = pm_log(b.lam_l); b.loglam_r = pm_log(b.lam_r);
         b.ll_tilde0 = ll_tilde0;
-        b.leaves = c->d_leaves; b.pool = c->d_pool;
+        b.leaves = c->d_leaves; b.pool = c->d_pool; b.pool_ptrs = c->d_pool_ptrs;
         b.Pmat = c->d_Pmat + (size_t)r * Kl * 32;
         b.pi = c->d_pi;
         b.logw_r = c->d_logw + (size_t)r * K;
@@ -526,8 +533,14 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r + 1], c->stream));
         launches += 2;
         {
-            CHK(phylo_comm_gather_rank(c->comm, c->d_logw + (size_t)r * K, c->d_ll + (size_t)r * K,
-                                       c->d_nodell + N + (size_t)r * K, K, c->stream, &c->err));
+            if (c->comm.transport != 0) {
+                double* rows[3] = {c->d_logw + (size_t)r * K, c->d_ll + (size_t)r * K, c->d_nodell + N + (size_t)r * K};
+                CHK(phylo_comm_allgather_inplace(c->comm, rows, 3, (size_t)Kl, c->stream, &c->err));
+                hipLaunchKernelGGL(pk_fix_rootll, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, c->d_rootll[nxt],
+                                   (const double*)(c->d_nodell + N + (size_t)r * K), K, N, N - r, c->k0, Kl);
+                CHK(launch_check(c, "pk_fix_rootll"));
+                ++launches;
+            }
             hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream,
                                (const double*)(c->d_logw + (size_t)r * K), K, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
                                c->d_lse + r);
@@ -631,8 +644,9 @@ int phylo_comm_init(phylo_ctx* c, int rank, int world, const char id[PHYLO_COMM_
     if (world < 1 || rank < 0 || rank >= world || !id) return fail(c, PHYLO_EINVAL, "bad rank/world");
     if (c->K % world != 0) return fail(c, PHYLO_EINVAL, "K = %d is not divisible by world = %d", c->K, world);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_sweep_state(c);                                   // peers may still map the old pool: drop it first
     int rc = phylo_comm_setup(&c->comm, rank, world, id, &c->err);
-    if (rc != PHYLO_OK) return rc;
+    if (rc != PHYLO_OK) { g_last_error = c->err; return rc; }
     c->rank = rank;
     c->world = world;
     c->Kloc = c->K / world;

@@ -440,7 +440,8 @@ struct pk_rank_args {
     const double* bl; const double* br;                   // [R][Kloc]
     double lam_l, lam_r, loglam_l, loglam_r, ll_tilde0;
     const double* leaves;                                 // [N][S][4]
-    double* pool;                                         // [(N-1)][Kloc][S][4]
+    double* pool;                                         // [(N-1)][Kloc][S][4]: this rank's nodes
+    const double* const* pool_ptrs;                       // [world]: every rank's pool as mapped in this process
     const double* Pmat;                                   // [Kloc][32] of this rank
     const double* pi;
     double* logw_r; double* ll_r;                         // [K] rows (global columns)
@@ -666,9 +667,12 @@ __device__ __forceinline__ double pk_dpp_odd(double v) {    // the value held by
 
 __device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int id) {
     const size_t node_sz = (size_t)a.S * 4;
-    // a child is a leaf (id < N) or a node of the local pool: id = N + rho*K + kappa
-    return id < a.N ? a.leaves + (size_t)id * node_sz
-                    : a.pool + ((size_t)((id - a.N) / a.K) * a.Kloc + ((id - a.N) % a.K - a.k0)) * node_sz;
+    // a child is a leaf (id < N, replicated on every GPU) or the node id = N + rho*K + kappa created at rank
+    // event rho by global particle kappa, which lives in the pool of rank kappa / Kloc (read in place over
+    // xGMI when that is not this GPU)
+    if (id < a.N) return a.leaves + (size_t)id * node_sz;
+    const int x = id - a.N, rho = x / a.K, kap = x - rho * a.K, owner = kap / a.Kloc;
+    return a.pool_ptrs[owner] + ((size_t)rho * a.Kloc + (kap - owner * a.Kloc)) * node_sz;
 }
 
 __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a) {
@@ -740,6 +744,15 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a
         a.ll_r[kg] = ll;
         a.logw_r[kg] = lw;
     }
+}
+
+// multi-GPU: after the all-gather of node log-likelihoods, complete the root tables of the other ranks'
+// particles with the value of the node each of them created at this rank event
+__global__ void pk_fix_rootll(double* __restrict__ rootll_new, const double* __restrict__ nodell_row, int K, int N, int n,
+                              int k0, int Kloc) {
+    const int kg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kg >= K || (kg >= k0 && kg < k0 + Kloc)) return;
+    rootll_new[(size_t)kg * N + (n - 2)] = nodell_row[kg];
 }
 
 // arithmetic probe

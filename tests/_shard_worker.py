@@ -1,0 +1,42 @@
+"""One rank of a sharded sweep (helper process of tests/test_gpu_sharded.py and of the CPU protocol test).
+usage: python tests/_shard_worker.py RANK WORLD K DATASET SEED JC OUT.npz [N_SWEEPS]"""
+import os
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    rank, world, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    dataset, seed, jc, out = sys.argv[4], int(sys.argv[5]), sys.argv[6] == '1', sys.argv[7]
+    n_sweeps = int(sys.argv[8]) if len(sys.argv) > 8 else 1
+    from phylo_amd import _ffi, model
+    from phylo_amd.datasets import load_dataset
+    from phylo_amd.rendezvous import exchange_comm_id
+    g = load_dataset(dataset)['genome']
+    N, S, _ = g.shape
+    Q = model.jc_Q() if jc else model.get_Q(model.init_y_q())
+    pi = model.get_stationary_probs(np.zeros(4) + 0.25)
+    lam = np.full(N - 1, 10.0)
+    ctx = _ffi.Context(K, N, S, device=int(os.environ.get('PHYLO_TEST_DEVICE', '0')))
+    ctx.set_leaves(g)
+    ctx.set_model(Q, pi, lam, lam, jc69_closed_form=jc)
+    cid = exchange_comm_id(rank, world, _ffi.comm_unique_id if rank == 0 else None)
+    ctx.comm_init(rank, world, cid)
+    res = None
+    for s in range(n_sweeps):                     # back-to-back sweeps reuse the node pool slabs
+        res = ctx.sweep(seed + s)
+    t = ctx.comm_max(float(rank))
+    assert t == world - 1, t
+    ctx.comm_barrier()
+    node = ctx.sweep_node(N - 2, ctx.K_local - 1)
+    np.savez(out, log_weights=res['log_weights'], log_likelihood=res['log_likelihood'], ancestors=res['ancestors'],
+             merges=res['merges'], left_branches=res['left_branches'], logZ=res['logZ'], node=node, k0=ctx.k0)
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,85 @@
+"""Sharded sweep on real hardware.  A one-GPU box cannot host several RCCL ranks (RCCL refuses duplicate
+devices), so several PROCESSES share GPU 0 and exchange the per-rank vectors through the hostshm transport
+(PHYLO_COMM=hostshm); the sharded bookkeeping, the node addressing and the hipIpc peer mappings of the node
+pools are the product's own.  The result must be bit-identical to the unsharded sweep and to the oracle.
+RCCL itself is exercised with a world of one rank."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as CO
+from oracle import cpu_ref as O
+from phylo_amd import _ffi
+from phylo_amd.datasets import load_dataset
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+PI = np.full((1, 4), 0.25)
+
+
+def run_world(world, K, dataset, seed, jc, n_sweeps=1, transport='hostshm', extra_env=None):
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, PHYLO_RDZV_DIR=tmp, MASTER_PORT=str(29000 + os.getpid() % 2000), PHYLO_COMM=transport)
+        env.update(extra_env or {})
+        procs = []
+        for r in range(world):
+            out = os.path.join(tmp, "r%d.npz" % r)
+            procs.append((out, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_shard_worker.py"), str(r),
+                                                 str(world), str(K), dataset, str(seed), '1' if jc else '0', out,
+                                                 str(n_sweeps)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        outs = []
+        for out, p in procs:
+            try:
+                log, _ = p.communicate(timeout=240)
+            except subprocess.TimeoutExpired:
+                for _, q in procs:
+                    q.kill()
+                raise
+            assert p.returncode == 0, log.decode()[-2000:]
+            outs.append(dict(np.load(out)))
+        return outs
+
+
+@pytest.mark.parametrize("world,K,jc", [(2, 64, True), (3, 96, False)])
+def test_sharded_sweep_bit_identical(world, K, jc):
+    dataset, seed, n_sweeps = 'primate_data', 4, 2
+    parts = run_world(world, K, dataset, seed, jc, n_sweeps=n_sweeps)
+    g = load_dataset(dataset)['genome']
+    N = g.shape[0]
+    Q = O.jc_Q() if jc else O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    ref = CO.sweep(g, Q, PI, lam, lam, K, seed + n_sweeps - 1, jc=jc, want_nodes=True)
+    Kl = K // world
+    for r, p in enumerate(parts):
+        assert int(p['k0']) == r * Kl
+        sl = slice(r * Kl, (r + 1) * Kl)
+        np.testing.assert_array_equal(p['ancestors'], ref['ancestors'][:, sl])          # global indices, bit-exact
+        np.testing.assert_array_equal(p['merges'], ref['merges'][:, sl])
+        assert np.array_equal(p['log_weights'].view(np.uint64), ref['log_weights'][:, sl].view(np.uint64))
+        assert np.array_equal(p['log_likelihood'].view(np.uint64), ref['log_likelihood'][:, sl].view(np.uint64))
+        assert float(p['logZ']) == ref['logZ']                                           # every rank holds the global log Z
+        assert np.array_equal(p['node'].view(np.uint64), ref['nodes'][N - 2, (r + 1) * Kl - 1].view(np.uint64))
+    # remote children were really exercised: some ancestor of a rank-0 particle lives on another rank
+    assert (parts[0]['ancestors'] >= Kl).any()
+
+
+def test_rccl_single_rank_world():
+    """RCCL communicator with one rank: ncclCommInitRank / grouped in-place all-gather on the real library."""
+    parts = run_world(1, 32, 'primate_data_wang', 1, True, transport='rccl', extra_env={'PHYLO_COMM_FORCE_RCCL': '1'})
+    g = load_dataset('primate_data_wang')['genome']
+    lam = np.full(8, 10.0)
+    ref = CO.sweep(g, O.jc_Q(), PI, lam, lam, 32, 1, jc=True)
+    assert np.array_equal(parts[0]['log_weights'].view(np.uint64), ref['log_weights'].view(np.uint64))
+    assert float(parts[0]['logZ']) == ref['logZ']
+
+
+def test_comm_init_rejects_bad_world():
+    g = load_dataset('primate_data_wang')['genome']
+    ctx = _ffi.Context(10, 9, 738)
+    with pytest.raises(_ffi.PhyloError):
+        ctx.comm_init(0, 3, b'\0' * 128)          # K not divisible by world
+    ctx.close()

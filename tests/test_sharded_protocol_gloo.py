@@ -1,0 +1,78 @@
+"""The N > 1 path on CPU: world_size-2 processes over torch.distributed (gloo) run the sharded protocol
+(oracle/sharded_ref.py: replicated integer state, one all-gather of three K-vectors per rank event, remote
+nodes fetched from their owner only when merged) and must reproduce the unsharded oracle sweep; also the
+file rendezvous that hands the RCCL id to the ranks."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _worker(rank, world, port, K, seed, tmp):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import cpu_ref as O
+    from oracle.sharded_ref import sweep_sharded
+    from phylo_amd.datasets import load_dataset
+    from phylo_amd.rendezvous import exchange_comm_id
+
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['PHYLO_RDZV_DIR'] = tmp
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    # the id hand-off used by bench.py / the shard workers
+    cid = exchange_comm_id(rank, world, (lambda: bytes(range(128))) if rank == 0 else None)
+    assert cid[:128] == bytes(range(128))
+
+    class Comm:
+        """all_gather over gloo; remote nodes: every rank publishes the nodes it owns that somebody may
+        read (test simplicity: an all_gather of this rank's node dict keys on demand would need an RPC; the
+        GPU path reads the owner's pool in place instead)."""
+
+        def __init__(self):
+            self.pool = None
+
+        def all_gather(self, arr):
+            t = torch.from_numpy(np.ascontiguousarray(arr))
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            return [o.numpy() for o in out]
+
+        def serve_begin(self, pool):
+            # exchange every rank's full pool (small test sizes) so that fetch_node can be answered locally
+            objs = [None] * world
+            dist.all_gather_object(objs, pool)
+            self.pools = objs
+
+        def serve_end(self):
+            self.pools = None
+
+        def fetch_node(self, owner, key):
+            return self.pools[owner][key]
+
+    g = load_dataset('primate_data_wang')['genome'][:, :120]
+    N = g.shape[0]
+    Q, pi, lam = O.get_Q(O.init_y_q()), np.full((1, 4), 0.25), np.full(N - 1, 10.0)
+    out = sweep_sharded(Comm(), rank, world, g, Q, pi, lam, lam, K, seed)
+    ref = O.sweep(g, Q, pi, lam, lam, K, seed)
+    np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
+    np.testing.assert_allclose(out['log_weights'], ref['log_weights'], rtol=1e-12)
+    assert abs(out['logZ'] - ref['logZ']) < 1e-9 * abs(ref['logZ'])
+    np.save(os.path.join(tmp, 'fetch%d.npy' % rank), np.array([out['remote_fetches']]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("K,seed", [(16, 0), (24, 3)])
+def test_sharded_protocol_world2(K, seed):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() * 7 + K) % 1000
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, port, K, seed, tmp), nprocs=2, join=True)
+        fetched = sum(int(np.load(os.path.join(tmp, 'fetch%d.npy' % r))[0]) for r in range(2))
+        assert fetched > 0, "the test never exercised a remote child"
