@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/:
+   profiles/<tag>_kernel_stats_{default,1stream}.csv  rocprofv3 --stats tables as produced
+   profiles/<tag>_summary.md                          per-kernel averages, HBM traffic of the merge kernel
+   profiles/pmc_traffic.json                          read by bench.py for roofline.traffic
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(src, pattern))
+    return f[0] if f else None
+
+
+lines = ["# rocprofv3 summary, round %s" % tag, "",
+         "Command: `python bench.py --steps 30 --warmup 3 --no-cpu-baseline` (primate.p N=12 S=898, GTR-init, K=2048;",
+         "default = 3 sweeps in flight; `--streams 1` = one sweep at a time).  Raw tables: `%s_kernel_stats_*.csv`." % tag, ""]
+for name in ("default", "1stream"):
+    st = one("trace_%s/*/*_kernel_stats.csv" % name)
+    if not st:
+        continue
+    shutil.copy(st, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, name)))
+    lines += ["## kernel stats (%s)" % name, "", "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(st)):
+        lines.append("| %s | %s | %.2f | %.2f | %.2f | %s |" % (r['Name'][:60], r['Calls'], float(r['AverageNs']) / 1e3,
+                                                         float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
+    log = open(os.path.join(src, "trace_%s.log" % name)).read()
+    js = [l for l in log.splitlines() if l.startswith('{"metric"')]
+    if js:
+        j = json.loads(js[-1])
+        lines += ["", "bench line under the profiler: value %.4g %s, ms_per_step %.4f" % (j['value'], j['unit'], j['ms_per_step']), ""]
+
+agg = {}
+for cn, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    f = one("%s/*/*_counter_collection.csv" % d)
+    if not f:
+        continue
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == cn:
+            per[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+    agg[cn] = {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
+if agg:
+    lines += ["## HBM traffic from PMC counters (separate passes; values in KB per dispatch as rocprofv3 reports them)", "",
+              "| kernel | FETCH_SIZE avg KB | WRITE_SIZE avg KB | dispatches |", "|---|---|---|---|"]
+    for k in sorted(set(agg.get("FETCH_SIZE", {})) | set(agg.get("WRITE_SIZE", {}))):
+        fz = agg.get("FETCH_SIZE", {}).get(k, (0.0, 0))
+        wz = agg.get("WRITE_SIZE", {}).get(k, (0.0, 0))
+        lines.append("| %s | %.1f | %.1f | %d |" % (k, fz[0], wz[0], max(fz[1], wz[1])))
+    fz = agg.get("FETCH_SIZE", {}).get("pk_rank_merge", (0.0, 0))[0]
+    wz = agg.get("WRITE_SIZE", {}).get("pk_rank_merge", (0.0, 0))[0]
+    hbm = (2.0 * fz + wz) * 1024.0
+    alg = 96.0 * 2048 * 898
+    lines += ["", "Merge kernel (`pk_rank_merge`), per launch: FETCH_SIZE %.0f KB is doubled (MI355X_MICROARCH.md, HBM: on gfx950" % fz,
+              "FETCH_SIZE reports half the bytes of a 16 B/lane coalesced stream), WRITE_SIZE %.0f KB is exact for 16 B/lane" % wz,
+              "streaming stores: HBM traffic = 2 x FETCH + WRITE = **%.1f MB** against **%.1f MB** algorithmic (96 B x K x S)." % (hbm / 1e6, alg / 1e6),
+              "The children are leaves (L2-resident, 345 KB) or nodes of the few ancestors that survive resampling, so almost all",
+              "reads are served on chip; the kernel's HBM stream is the 59 MB it writes.", ""]
+    json.dump({"workload": "primate.p", "K": 2048, "kernel": "pk_rank_merge", "hbm_bytes_per_launch": hbm,
+               "fetch_size_kb": fz, "write_size_kb": wz, "correction": "2*FETCH_SIZE + WRITE_SIZE (KB -> bytes x1024)",
+               "round": tag}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
