@@ -42,12 +42,14 @@ def parse():
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--streams', type=int, default=0,
                    help='independent sweeps kept in flight on separate HIP streams (0 = 3 on one GPU, 1 when sharded)')
+    p.add_argument('--twisting', action='store_true', help='twisted proposal (vncsmc.py); BASELINE config 2')
+    p.add_argument('--M', type=int, default=1, help='sub-samples of the twisted proposal')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline duration')
     return p.parse_args()
 
 
-def cpu_baseline(g, Q, pi, lam, jc, K_gpu, seconds):
+def cpu_baseline(g, Q, pi, lam, jc, K_gpu, seconds, twist_M=0):
     """The C oracle (reference dataflow, OpenMP) timed on this host's cores on a bounded sample."""
     from oracle import c_oracle as CO
     N, S, _ = g.shape
@@ -58,8 +60,14 @@ def cpu_baseline(g, Q, pi, lam, jc, K_gpu, seconds):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, int(os.environ.get('PHYLO_CPU_THREADS', '16'))))
     CO.set_threads(cores)
+    def one(K, seed):
+        if twist_M:
+            CO.sweep_twisted(g, Q, pi, lam, lam, K, twist_M, seed, jc=jc)
+        else:
+            CO.sweep(g, Q, pi, lam, lam, K, seed, jc=jc)
+
     t0 = time.perf_counter()
-    CO.sweep(g, Q, pi, lam, lam, 64, 0, jc=jc)
+    one(64, 0)
     per_particle = (time.perf_counter() - t0) / 64
     K = int(min(K_gpu, max(64, seconds / max(per_particle, 1e-9))))
     K = 1 << (K.bit_length() - 1)
@@ -67,9 +75,9 @@ def cpu_baseline(g, Q, pi, lam, jc, K_gpu, seconds):
     n = min(n, 200)
     t0 = time.perf_counter()
     for s in range(n):
-        CO.sweep(g, Q, pi, lam, lam, K, s, jc=jc)
+        one(K, s)
     dt = time.perf_counter() - t0
-    units = float(K) * S * (N - 1) * n
+    units = float(K) * S * ((N - 1) + (twist_M * (N + 1) * N * (N - 1) / 6.0 if twist_M else 0.0)) * n
     return {"value": units / dt, "unit": "particle-site-likelihoods/s", "cores": cores, "kind": "port",
             "sample": "%d sweep(s) of the same alignment at K=%d (oracle/csrc/oracle.c, reference dataflow, %d OpenMP threads, %.1f s)"
                       % (n, K, cores, dt)}
@@ -115,9 +123,11 @@ def main():
         cid = exchange_comm_id(rank, world, _ffi.comm_unique_id if rank == 0 else None)
         ctx.comm_init(rank, world, cid)
 
+    sweep_flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if a.twisting else 0)
+
     def run(n, seed0):
         for s in range(n):
-            ctxs[s % n_streams].sweep_async(seed0 + s)
+            ctxs[s % n_streams].sweep_async(seed0 + s, flags=sweep_flags, M=a.M)
         for c in ctxs:
             c.synchronize()
 
@@ -134,13 +144,13 @@ def main():
     # Felsenstein merge): average launch duration from HIP events on the ctx stream, nothing else in flight
     t1 = time.perf_counter()
     for s in range(10):
-        ctx.sweep_async(a.seed + s)
+        ctx.sweep_async(a.seed + s, flags=sweep_flags, M=a.M)
     ctx.synchronize()
     single_ms = (time.perf_counter() - t1) / 10 * 1e3
     prof_sweeps = 3
     merge_ms, merge_n = 0.0, 0
     for s in range(prof_sweeps):
-        ctx.sweep_async(a.seed + s, flags=_ffi.FLAGS_DEFAULT | _ffi.TIME_KERNELS)
+        ctx.sweep_async(a.seed + s, flags=sweep_flags | _ffi.TIME_KERNELS, M=a.M)
         st = ctx.sweep_fetch(arrays=False)['stats']
         merge_ms += st['merge_ms']
         merge_n += st['merge_launches']
@@ -159,13 +169,16 @@ def main():
 
     if rank == 0:
         units_per_step = float(K_global) * S * (N - 1)
+        if a.twisting:                             # + K M S C(N+1,3) look-ahead merges
+            units_per_step += float(K_global) * a.M * S * ((N + 1) * N * (N - 1) / 6.0)
         line = {
             "metric": "particle-site-likelihoods/sec", "value": units_per_step * a.steps / dt,
             "unit": "particle-site-likelihoods/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if a.synthetic else "primate.p alignment (real sites), untrained model parameters",
             "config": {"workload": "%s N=%d S=%d, %s, K=%d per GPU (K_total=%d), lambda=10, full sweep of %d rank events"
-                                   % (wname, N, S, "JC69" if a.jcmodel else "GTR-init (jcmodel=false)", a.n_particles, K_global, N - 1),
+                                   % (wname, N, S, ("JC69" if a.jcmodel else "GTR-init (jcmodel=false)") + (" + twisting M=%d" % a.M if a.twisting else ""),
+                                      a.n_particles, K_global, N - 1),
                        "parallelism": "particles sharded over %d GPU(s), global resampling" % world,
                        "sweeps_in_flight": n_streams},
             "single_sweep_ms": single_ms,
@@ -176,7 +189,7 @@ def main():
                          "sweep_frac_of_peak": (96.0 * units_per_step / world) / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS},
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds, a.M if a.twisting else 0)
         print(json.dumps(line), flush=True)
     for c in ctxs:
         c.close()

@@ -130,3 +130,29 @@ def sweep(genome, Q, pi, lam_l, lam_r, K, seed, flags=1, jc=False, want_nodes=Fa
     if want_nodes:
         out['nodes'] = nodes
     return out
+
+
+def sweep_twisted(genome, Q, pi, lam_l, lam_r, K, M, seed, jc=False, want_nodes=False, want_potentials=False):
+    genome, Q, pi, lam_l, lam_r = _c(genome), _c(Q), _c(pi).reshape(-1), _c(lam_l), _c(lam_r)
+    N, S = genome.shape[0], genome.shape[1]
+    R = N - 1
+    out = {
+        'log_weights': np.empty((R, K)), 'log_likelihood': np.empty((R, K)),
+        'left_branches': np.empty((R, K)), 'right_branches': np.empty((R, K)),
+        'merges': np.empty((R, K, 2), dtype=np.int32), 'ancestors': np.empty((max(R - 1, 0), K), dtype=np.int64),
+    }
+    nodes = np.empty((R, K, S, 4)) if want_nodes else None
+    pots = np.empty((R, K, (N * (N - 1) // 2) * M)) if want_potentials else None
+    z = C.c_double()
+    rc = lib().ora_sweep_twisted(_opt(genome), _opt(Q), _opt(pi), _opt(lam_l), _opt(lam_r), C.c_int(int(jc)), C.c_int(K),
+                                 C.c_int(N), C.c_int(S), C.c_int(M), C.c_uint64(seed), _opt(out['log_weights']),
+                                 _opt(out['log_likelihood']), _opt(out['left_branches']), _opt(out['right_branches']),
+                                 _opt(out['merges']), _opt(out['ancestors']), C.byref(z), _opt(nodes), _opt(pots))
+    if rc != 0:
+        raise MemoryError("ora_sweep_twisted")
+    out['logZ'] = z.value
+    if want_nodes:
+        out['nodes'] = nodes
+    if want_potentials:
+        out['potentials'] = pots
+    return out

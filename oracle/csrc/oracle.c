@@ -350,3 +350,171 @@ int ora_sweep(const double* genome /*[N][S][4]*/, const double* Q, const double*
     free(ll_tilde); free(cdf); free(idx); free(lse);
     return 0;
 }
+
+/* ---- T: the twisted / nested proposal, vncsmc.py:295-416 + 432-499, same dataflow as ora_sweep -------- */
+/* potentials_out (may be NULL): [(N-1)][K][Jmax] raw (un-normalised) look-ahead potentials, Jmax = C(N,2)*M,
+ * rows padded with zeros (test surface for the potentials kernel). */
+int ora_sweep_twisted(const double* genome, const double* Q, const double* pi, const double* lam_l, const double* lam_r,
+                      int jc, int K, int N, int S, int M, uint64_t seed, double* log_weights, double* log_lik,
+                      double* lbranch, double* rbranch, int32_t* merges, int64_t* ancestors, double* logZ,
+                      double* nodes_out, double* potentials_out) {
+    const int R = N - 1;
+    const size_t node = (size_t)S * 4, part = (size_t)N * node;
+    const int Jmax = (N * (N - 1) / 2) * M;
+    double* coreA = (double*)malloc((size_t)K * part * sizeof(double));
+    double* coreB = (double*)malloc((size_t)K * part * sizeof(double));
+    int32_t* recA = (int32_t*)malloc((size_t)K * N * sizeof(int32_t));
+    int32_t* recB = (int32_t*)malloc((size_t)K * N * sizeof(int32_t));
+    double* lw = (double*)malloc((size_t)R * K * sizeof(double));
+    double* ll = (double*)malloc((size_t)R * K * sizeof(double));
+    double* bls = (double*)malloc((size_t)R * K * sizeof(double));
+    double* brs = (double*)malloc((size_t)R * K * sizeof(double));
+    double* ll_tilde = (double*)malloc((size_t)K * sizeof(double));
+    uint64_t* cdf = (uint64_t*)malloc((size_t)K * sizeof(uint64_t));
+    double* lse = (double*)malloc((size_t)R * sizeof(double));
+    if (!coreA || !coreB || !recA || !recB || !lw || !ll || !bls || !brs || !ll_tilde || !cdf || !lse) return -1;
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; ++k) {
+        memcpy(coreA + (size_t)k * part, genome, part * sizeof(double));
+        for (int i = 0; i < N; ++i) recA[(size_t)k * N + i] = 1;
+    }
+    const double ll_tilde0 = ora_log(1.0 / (double)K);
+    for (int k = 0; k < K; ++k) ll_tilde[k] = ll_tilde0;
+    int oom = 0;
+    for (int r = 0; r < R; ++r) {
+        const int n = N - r, J = (n * (n - 1) / 2) * M;
+        if (r > 0) {
+            lse[r - 1] = weights_prepare(lw + (size_t)(r - 1) * K, K, cdf);
+#pragma omp parallel for schedule(static)
+            for (int k = 0; k < K; ++k) {
+                uint32_t x[4];
+                ora_philox((uint32_t)k, (uint32_t)r, 2u, 0u, seed, x);
+                uint64_t Rr = ((uint64_t)x[1] << 32) | x[0];
+                int a = cdf_search(cdf, K, ora_mulhi64(Rr, cdf[K - 1]));
+                memcpy(coreB + (size_t)k * part, coreA + (size_t)a * part, (size_t)n * node * sizeof(double));
+                memcpy(recB + (size_t)k * N, recA + (size_t)a * N, (size_t)n * sizeof(int32_t));
+                ll_tilde[k] = ll[(size_t)(r - 1) * K + a];
+                if (ancestors) ancestors[(size_t)(r - 1) * K + k] = a;
+            }
+            double* tc = coreA; coreA = coreB; coreB = tc;
+            int32_t* tr_ = recA; recA = recB; recB = tr_;
+        }
+        const double laml = lam_l[r], lamr = lam_r[r];
+        const double loglaml = ora_log(laml), loglamr = ora_log(lamr);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int k = 0; k < K; ++k) {
+            const double* src = coreA + (size_t)k * part;
+            double* dst = coreB + (size_t)k * part;
+            const int32_t* rs = recA + (size_t)k * N;
+            int32_t* rd = recB + (size_t)k * N;
+            double* pot = (double*)malloc((size_t)J * sizeof(double));
+            double* wv = (double*)malloc((size_t)J * sizeof(double));
+            double* tmp = (double*)malloc(node * sizeof(double));
+            double rowll[1024];
+            if (!pot || !wv || !tmp) { oom = 1; free(pot); free(wv); free(tmp); continue; }
+            for (int x = 0; x < n; ++x) rowll[x] = row_loglik(pi, src + (size_t)x * node, S);
+            /* compute_potentials, vncsmc.py:379-416 (pairs r1 < r2 lexicographic, M sub-samples each) */
+            int t = 0;
+            for (int r1 = 0; r1 < n - 1; ++r1)
+                for (int r2 = r1 + 1; r2 < n; ++r2, ++t)
+                    for (int m = 0; m < M; ++m) {
+                        const int j = t * M + m;
+                        uint32_t x[4];
+                        ora_philox((uint32_t)k, (uint32_t)r, 3u, (uint32_t)j, seed, x);
+                        const double tl = (-ora_log(ora_unit_oc(x[0], x[1]))) / laml;
+                        const double tr = (-ora_log(ora_unit_oc(x[2], x[3]))) / lamr;
+                        double Pl[16], Pr[16];
+                        if (jc) { ora_jc69(tl, Pl); ora_jc69(tr, Pr); } else { ora_expm4(Q, tl, Pl); ora_expm4(Q, tr, Pr); }
+                        const double* L = src + (size_t)r1 * node;
+                        const double* Rr = src + (size_t)r2 * node;
+                        for (int s = 0; s < S; ++s) merge_site(L + (size_t)s * 4, Rr + (size_t)s * 4, Pl, Pr, tmp + (size_t)s * 4);
+                        double jp = row_loglik(pi, tmp, S) + (-log_double_factorial_count(rs[r1] + rs[r2]));
+                        jp = jp - (rowll[r1] + (-log_double_factorial_count(rs[r1])));
+                        jp = jp - (rowll[r2] + (-log_double_factorial_count(rs[r2])));
+                        pot[j] = jp;
+                    }
+            if (potentials_out) {
+                double* po = potentials_out + ((size_t)r * K + k) * Jmax;
+                for (int j = 0; j < Jmax; ++j) po[j] = j < J ? pot[j] : 0.0;
+            }
+            /* normalise and draw one (pair, sub-sample), vncsmc.py:298-301, 407 */
+            double mx = -ORA_INF;
+            for (int j = 0; j < J; ++j) if (!ora_isnan(pot[j]) && pot[j] > mx) mx = pot[j];
+            const int all_bad = !(mx > -ORA_INF) || mx == ORA_INF;
+            double ssum = 0.0;
+            uint64_t run = 0, thr;
+            for (int j = 0; j < J; ++j) {
+                wv[j] = all_bad ? 1.0 : (ora_isnan(pot[j]) ? 0.0 : ora_exp(pot[j] - mx));
+                ssum = ssum + wv[j];
+            }
+            uint64_t total = 0;
+            for (int j = 0; j < J; ++j) total += all_bad ? 1ull : (uint64_t)(wv[j] * 17592186044416.0);
+            {
+                uint32_t x[4];
+                ora_philox((uint32_t)k, (uint32_t)r, 3u, 0xFFFFFFFFu, seed, x);
+                thr = ora_mulhi64(((uint64_t)x[1] << 32) | x[0], total);
+            }
+            int jsel = J - 1;
+            for (int j = 0; j < J; ++j) {
+                run += all_bad ? 1ull : (uint64_t)(wv[j] * 17592186044416.0);
+                if (run > thr) { jsel = j; break; }
+            }
+            const double logq = pot[jsel] - ((all_bad ? 0.0 : mx) + ora_log(ssum));
+            /* chosen pair and its sub-sample's branches (vncsmc.py:301, 315-320) */
+            int il = 0, ir = 1;
+            t = 0;
+            for (int r1 = 0; r1 < n - 1; ++r1)
+                for (int r2 = r1 + 1; r2 < n; ++r2, ++t)
+                    if (t == jsel / M) { il = r1; ir = r2; }
+            uint32_t x[4];
+            ora_philox((uint32_t)k, (uint32_t)r, 3u, (uint32_t)jsel, seed, x);
+            const double tl = (-ora_log(ora_unit_oc(x[0], x[1]))) / laml;
+            const double tr = (-ora_log(ora_unit_oc(x[2], x[3]))) / lamr;
+            bls[(size_t)r * K + k] = tl;
+            brs[(size_t)r * K + k] = tr;
+            double Pl[16], Pr[16];
+            if (jc) { ora_jc69(tl, Pl); ora_jc69(tr, Pr); } else { ora_expm4(Q, tl, Pl); ora_expm4(Q, tr, Pr); }
+            int nrem = 0;
+            for (int i = n - 1; i >= 0; --i) {                     /* remaining slots, descending (vncsmc.py:305) */
+                if (i == il || i == ir) continue;
+                memcpy(dst + (size_t)nrem * node, src + (size_t)i * node, node * sizeof(double));
+                rd[nrem] = rs[i];
+                ++nrem;
+            }
+            double* nw = dst + (size_t)nrem * node;
+            for (int s = 0; s < S; ++s) merge_site(src + (size_t)il * node + (size_t)s * 4, src + (size_t)ir * node + (size_t)s * 4, Pl, Pr, nw + (size_t)s * 4);
+            rd[nrem] = rs[il] + rs[ir];
+            if (nodes_out) memcpy(nodes_out + ((size_t)r * K + k) * node, nw, node * sizeof(double));
+            if (merges) { merges[((size_t)r * K + k) * 2] = il; merges[((size_t)r * K + k) * 2 + 1] = ir; }
+            double fl = 0.0, fp = 0.0;
+            int vminus = 0;
+            for (int xr = 0; xr < n - 1; ++xr) {
+                fl = fl + row_loglik(pi, dst + (size_t)xr * node, S);
+                fp = fp + (-log_double_factorial_count(rd[xr]));
+                vminus += rd[xr] - (rd[xr] == 1 ? 1 : 0);
+            }
+            double lp = 0.0, rp = 0.0;
+            for (int j = 0; j <= r; ++j) {
+                lp = lp + ((-laml) * bls[(size_t)j * K + k] + loglaml);
+                rp = rp + ((-lamr) * brs[(size_t)j * K + k] + loglamr);
+            }
+            const double llr = ((fl + fp) + lp) + rp;
+            const double paren = ((loglaml - laml * tl) + loglamr) - lamr * tr;
+            ll[(size_t)r * K + k] = llr;
+            lw[(size_t)r * K + k] = (((llr - ll_tilde[k]) - paren) + ora_log((double)vminus)) - logq;   /* vncsmc.py:489-491 */
+            free(pot); free(wv); free(tmp);
+        }
+        { double* tc = coreA; coreA = coreB; coreB = tc; int32_t* tr_ = recA; recA = recB; recB = tr_; }
+    }
+    lse[R - 1] = weights_prepare(lw + (size_t)(R - 1) * K, K, NULL);
+    double z = 0.0;
+    for (int r = 0; r < R; ++r) z = z + lse[r];
+    if (logZ) *logZ = z;
+    if (log_weights) memcpy(log_weights, lw, (size_t)R * K * sizeof(double));
+    if (log_lik) memcpy(log_lik, ll, (size_t)R * K * sizeof(double));
+    if (lbranch) memcpy(lbranch, bls, (size_t)R * K * sizeof(double));
+    if (rbranch) memcpy(rbranch, brs, (size_t)R * K * sizeof(double));
+    free(coreA); free(coreB); free(recA); free(recB); free(lw); free(ll); free(bls); free(brs);
+    free(ll_tilde); free(cdf); free(lse);
+    return oom ? -1 : 0;
+}

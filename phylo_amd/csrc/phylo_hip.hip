@@ -56,6 +56,10 @@ struct phylo_ctx {
     uint64_t* d_cdf[2] = {nullptr, nullptr};   // [K], double-buffered across rank events
     unsigned int* d_counter = nullptr;   // (unused)
     const double** d_pool_ptrs = nullptr; // [world] pool base of every rank (peer mappings)
+    // twisted proposal (allocated on first use)
+    int32_t *d_roots_ad = nullptr, *d_cnt_ad = nullptr;
+    double *d_rootll_ad = nullptr, *d_chosen = nullptr, *d_tw_b = nullptr, *d_tw_P = nullptr, *d_pot = nullptr;
+    size_t tw_capacity = 0;              // in (particle, sub-sample) entries
     phylo_stats stats{};
     uint32_t last_flags = 0;
     int n_merge_events = 0;
@@ -134,6 +138,12 @@ int launch_check(phylo_ctx* ctx, const char* what) {
 }
 
 void free_sweep_state(phylo_ctx* c) {
+    void* tw[] = {c->d_roots_ad, c->d_cnt_ad, c->d_rootll_ad, c->d_chosen, c->d_tw_b, c->d_tw_P, c->d_pot};
+    for (void* p : tw)
+        if (p) (void)hipFree(p);
+    c->d_roots_ad = c->d_cnt_ad = nullptr;
+    c->d_rootll_ad = c->d_chosen = c->d_tw_b = c->d_tw_P = c->d_pot = nullptr;
+    c->tw_capacity = 0;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
                     c->d_roots[0], c->d_roots[1], c->d_cnt[0], c->d_cnt[1], c->d_child, c->d_merges, c->d_anc,
                     c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1], (void*)c->d_pool_ptrs};
@@ -481,8 +491,28 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     (void)M;
     if (!c->have_leaves || !c->have_model)
         return fail(c, PHYLO_ESTATE, "phylo_set_leaves and phylo_set_model must be called before a sweep");
-    if (flags & PHYLO_TWISTING) return fail(c, PHYLO_EINVAL, "PHYLO_TWISTING is not implemented in this build");
     const int N = c->N, K = c->K, Kl = c->Kloc, S = c->S, R = N - 1;
+    const bool twist = (flags & PHYLO_TWISTING) != 0;
+    if (twist) {
+        if (M < 1 || M > PK_TWIST_MAX_M) return fail(c, PHYLO_EINVAL, "twisting needs 1 <= M <= %d (got %d)", PK_TWIST_MAX_M, M);
+        const size_t Jmax = (size_t)(N * (N - 1) / 2) * M;
+        if (Jmax > PK_TWIST_MAX_J) return fail(c, PHYLO_EINVAL, "twisting: C(N,2)*M = %zu exceeds %d", Jmax, PK_TWIST_MAX_J);
+        if (!c->d_roots_ad) {
+            CHK(dalloc(c, &c->d_roots_ad, (size_t)K * N));
+            CHK(dalloc(c, &c->d_cnt_ad, (size_t)K * N));
+            CHK(dalloc(c, &c->d_rootll_ad, (size_t)K * N));
+            CHK(dalloc(c, &c->d_chosen, (size_t)K));
+        }
+        if (c->tw_capacity < (size_t)Kl * Jmax) {
+            if (c->d_tw_b) { (void)hipFree(c->d_tw_b); (void)hipFree(c->d_tw_P); (void)hipFree(c->d_pot); }
+            c->d_tw_b = c->d_tw_P = c->d_pot = nullptr;
+            c->tw_capacity = 0;
+            CHK(dalloc(c, &c->d_tw_b, (size_t)Kl * Jmax * 2));
+            CHK(dalloc(c, &c->d_tw_P, (size_t)Kl * Jmax * 32));
+            CHK(dalloc(c, &c->d_pot, (size_t)Kl * Jmax));
+            c->tw_capacity = (size_t)Kl * Jmax;
+        }
+    }
     const bool timek = (flags & PHYLO_TIME_KERNELS) != 0;
     if (timek && (int)c->kev.size() < 2 * R) {
         while ((int)c->kev.size() < 2 * R) {
@@ -494,9 +524,11 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     int launches = 0;
     const size_t lds = pk_book_lds_bytes(N);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    hipLaunchKernelGGL(pk_sweep_draws, dim3(cdiv(2L * R * Kl, 64)), dim3(64), 0, c->stream, c->d_Q, c->d_lam_l, c->d_lam_r,
-                       c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat);
-    CHK(launch_check(c, "pk_sweep_draws"));
+    if (!twist) {
+        hipLaunchKernelGGL(pk_sweep_draws, dim3(cdiv(2L * R * Kl, 64)), dim3(64), 0, c->stream, c->d_Q, c->d_lam_l, c->d_lam_r,
+                           c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat);
+        CHK(launch_check(c, "pk_sweep_draws"));
+    }
     hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream, c->d_roots[0], c->d_cnt[0],
                        c->d_rootll[0], (const double*)c->d_nodell, K, N);
     CHK(launch_check(c, "pk_init_tables"));
@@ -525,13 +557,40 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         b.ll_r = c->d_ll + (size_t)r * K;
         b.merges = c->d_merges; b.ancestors = c->d_anc;
         b.child = c->d_child; b.aux = c->d_aux;
-        hipLaunchKernelGGL(pk_rank_book, dim3(K), dim3(64), lds, c->stream, b);
-        CHK(launch_check(c, "pk_rank_book"));
+        if (twist) {
+            pk_twist_args ta{};
+            ta.a = b;
+            ta.M = M;
+            ta.J = ((N - r) * (N - r - 1) / 2) * M;
+            ta.roots_ad = c->d_roots_ad; ta.cnt_ad = c->d_cnt_ad; ta.rootll_ad = c->d_rootll_ad;
+            ta.tw_b = c->d_tw_b; ta.tw_P = c->d_tw_P; ta.pot = c->d_pot; ta.chosen = c->d_chosen;
+            ta.Pmat_r = c->d_Pmat + (size_t)r * Kl * 32;
+            ta.bl_r = c->d_bl + (size_t)r * Kl; ta.br_r = c->d_br + (size_t)r * Kl;
+            hipLaunchKernelGGL(pk_twist_adopt, dim3(K), dim3(64), 0, c->stream, ta);
+            CHK(launch_check(c, "pk_twist_adopt"));
+            hipLaunchKernelGGL(pk_twist_draws, dim3(cdiv(2L * Kl * ta.J, 64)), dim3(64), 0, c->stream, ta, (const double*)c->d_Q, c->jc);
+            CHK(launch_check(c, "pk_twist_draws"));
+            hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((size_t)Kl * (ta.J / M))), dim3(PK_COLS), 0, c->stream, ta);
+            CHK(launch_check(c, "pk_twist_potentials"));
+            hipLaunchKernelGGL(pk_twist_choose, dim3(Kl), dim3(64), (size_t)ta.J * 8, c->stream, ta);
+            CHK(launch_check(c, "pk_twist_choose"));
+            if (c->comm.transport != 0) {
+                double* rows[1] = {c->d_chosen};
+                CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, (size_t)Kl, c->stream, &c->err));
+            }
+            hipLaunchKernelGGL(pk_twist_tables, dim3(cdiv(K, 128)), dim3(128), 0, c->stream, ta);
+            CHK(launch_check(c, "pk_twist_tables"));
+            launches += 5;
+        } else {
+            hipLaunchKernelGGL(pk_rank_book, dim3(K), dim3(64), lds, c->stream, b);
+            CHK(launch_check(c, "pk_rank_book"));
+            ++launches;
+        }
         if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r], c->stream));
         hipLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
         CHK(launch_check(c, "pk_rank_merge"));
         if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r + 1], c->stream));
-        launches += 2;
+        ++launches;
         {
             if (c->comm.transport != 0) {
                 double* rows[3] = {c->d_logw + (size_t)r * K, c->d_ll + (size_t)r * K, c->d_nodell + N + (size_t)r * K};
@@ -558,6 +617,11 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     c->stats.n_launches = launches;
     c->stats.units = (double)Kl * S * R;
     c->stats.alg_bytes = 96.0 * c->stats.units;
+    if (twist) {                                           // + K M S C(N+1,3) look-ahead merges, 64 B each (no store)
+        const double ut = (double)Kl * M * S * ((double)(N + 1) * N * (N - 1) / 6.0);
+        c->stats.units += ut;
+        c->stats.alg_bytes += 64.0 * ut;
+    }
     return PHYLO_OK;
 }
 

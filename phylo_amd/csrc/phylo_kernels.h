@@ -755,6 +755,230 @@ __global__ void pk_fix_rootll(double* __restrict__ rootll_new, const double* __r
     rootll_new[(size_t)kg * N + (n - 2)] = nodell_row[kg];
 }
 
+// ================================================================================================
+// T: the twisted / nested proposal (vncsmc.py:295-416, 432-499).  Per rank event:
+//   pk_twist_adopt      resampling index + adoption of the ancestor's root table (no pick yet)
+//   pk_twist_draws      branch lengths and transition matrices of every (particle, pair, sub-sample)
+//   pk_twist_potentials look-ahead potential post(merged) - post(left) - post(right) of every one of them
+//   pk_twist_choose     normalise per particle, draw ONE (pair, sub-sample), weight terms, children
+//   pk_twist_tables     new root tables from the chosen pair (all particles; after the all-gather of the
+//                       choices when sharded), remaining roots in DESCENDING slot order (vncsmc.py:305)
+// then the ordinary pk_rank_merge.  Sub-sample j = t*M + m of pair t (lexicographic r1 < r2).
+// ================================================================================================
+#define PK_TWIST_MAX_M 16
+#define PK_TWIST_MAX_J 4096
+#define PK_TWIST_DRAW_BLOCK 0xFFFFFFFFu
+
+struct pk_twist_args {
+    pk_rank_args a;                  // shared fields (tables, cdf, rates, outputs)
+    int M, J;                        // J = C(n,2) * M
+    int32_t* roots_ad; int32_t* cnt_ad; double* rootll_ad;   // [K][N] adopted (resampled) tables
+    double* tw_b;                    // [Kloc][J][2] branch lengths
+    double* tw_P;                    // [Kloc][J][32] transition matrices
+    double* pot;                     // [Kloc][J] potentials
+    double* chosen;                  // [K] chosen j per global particle (as double: travels with the RCCL all-gather)
+    double* Pmat_r;                  // [Kloc][32] matrices of the chosen sub-sample (input of pk_rank_merge)
+    double* bl_r; double* br_r;      // [Kloc] rows r of the branch-length history
+};
+
+__global__ __launch_bounds__(64) void pk_twist_adopt(const pk_twist_args ta) {
+    const pk_rank_args& a = ta.a;
+    const int kg = blockIdx.x, lane = threadIdx.x, N = a.N, n = a.n;
+    int anc = kg;
+    if (a.r > 0) {
+        const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_RESAMPLE, 0u, a.seed);
+        anc = pk_cdf_search_wave(a.cdf, a.K, ((uint64_t)x.y << 32) | x.x, lane);
+    }
+    for (int i = lane; i < n; i += 64) {
+        ta.roots_ad[(size_t)kg * N + i] = a.roots_old[(size_t)anc * N + i];
+        ta.cnt_ad[(size_t)kg * N + i] = a.cnt_old[(size_t)anc * N + i];
+        ta.rootll_ad[(size_t)kg * N + i] = a.rootll_old[(size_t)anc * N + i];
+    }
+    const bool local = kg >= a.k0 && kg < a.k0 + a.Kloc;
+    if (local && lane == 0) {
+        const int k = kg - a.k0;
+        a.aux[(size_t)k * PK_AUX + AUX_LL_TILDE] = (a.r > 0) ? a.ll_prev[anc] : a.ll_tilde0;
+        if (a.r > 0) a.ancestors[(size_t)(a.r - 1) * a.Kloc + k] = anc;
+    }
+}
+
+__global__ __launch_bounds__(64) void pk_twist_draws(const pk_twist_args ta, const double* __restrict__ Q, int jc) {
+    const pk_rank_args& a = ta.a;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2L * a.Kloc * ta.J) return;
+    const int side = (int)(t & 1);
+    const long i = t >> 1;
+    const int k = (int)(i / ta.J), j = (int)(i - (long)k * ta.J);
+    const pm_u32x4 x = pm_philox4x32((uint32_t)(a.k0 + k), (uint32_t)a.r, PM_STREAM_TWIST, (uint32_t)j, a.seed);
+    const double b = side ? (-pm_log(pm_unit_oc(x.z, x.w))) / a.lam_r : (-pm_log(pm_unit_oc(x.x, x.y))) / a.lam_l;
+    ta.tw_b[i * 2 + side] = b;
+    double q[16], p[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) q[u] = Q[u];
+    if (jc) pm_jc69(b, p); else pm_expm4(q, b, p);
+    double* out = ta.tw_P + i * 32 + side * 16;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) out[u] = p[u];
+}
+
+// one workgroup per (local particle, pair): rows of the two roots are read once per site step and reused for
+// the M sub-samples; nothing is stored but the M potentials.
+__global__ __launch_bounds__(PK_COLS) void pk_twist_potentials(const pk_twist_args ta) {
+    __shared__ double sh4[4];
+    const pk_rank_args& a = ta.a;
+    const int n = a.n, M = ta.M, npairs = n * (n - 1) / 2;
+    const int k = blockIdx.x / npairs, t = blockIdx.x - k * npairs, kg = a.k0 + k;
+    int r1 = 0, rem = t;                             // decode the lexicographic pair index
+    while (rem >= n - 1 - r1) { rem -= n - 1 - r1; ++r1; }
+    const int r2 = r1 + 1 + rem;
+    const int32_t* ro = ta.roots_ad + (size_t)kg * a.N;
+    const double* Lp = pk_node_ptr(a, ro[r1]);
+    const double* Rp = pk_node_ptr(a, ro[r2]);
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    const double* Pbase = ta.tw_P + ((size_t)k * ta.J + (size_t)t * M) * 32;
+    double acc[PK_TWIST_MAX_M];
+#pragma unroll
+    for (int m = 0; m < PK_TWIST_MAX_M; ++m) acc[m] = 0.0;
+    for (int s = threadIdx.x; s < a.S; s += PK_COLS) {
+        double Lv[4], Rv[4];
+        pk_load4(Lp + (size_t)s * 4, Lv);
+        pk_load4(Rp + (size_t)s * 4, Rv);
+#pragma unroll
+        for (int m = 0; m < PK_TWIST_MAX_M; ++m) {
+            if (m < M) {
+                const double* P = Pbase + m * 32;
+                double o[4];
+                pk_merge_site(Lv, Rv, P, P + 16, o);
+                acc[m] = acc[m] + pm_log(pk_site_lik(pi, o));
+            }
+        }
+    }
+    const int c1 = ta.cnt_ad[(size_t)kg * a.N + r1], c2 = ta.cnt_ad[(size_t)kg * a.N + r2];
+    const double l1 = ta.rootll_ad[(size_t)kg * a.N + r1], l2 = ta.rootll_ad[(size_t)kg * a.N + r2];
+#pragma unroll
+    for (int m = 0; m < PK_TWIST_MAX_M; ++m) {
+        if (m < M) {
+            const double tot = pk_block_canon_sum(acc[m], sh4);
+            if (threadIdx.x == 0) {
+                const int c12 = c1 + c2;
+                double jp = tot + (-a.ldf[c12 < a.ldf_n ? c12 : a.ldf_n]);
+                jp = jp - (l1 + (-a.ldf[c1 < a.ldf_n ? c1 : a.ldf_n]));
+                jp = jp - (l2 + (-a.ldf[c2 < a.ldf_n ? c2 : a.ldf_n]));
+                ta.pot[(size_t)k * ta.J + (size_t)t * M + m] = jp;
+            }
+        }
+    }
+}
+
+// one wave per local particle: softmax over its J potentials, one categorical draw (integer CDF), the weight
+// terms of vncsmc.py:472-491 for the chosen pair.
+__global__ __launch_bounds__(64) void pk_twist_choose(const pk_twist_args ta) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const pk_rank_args& a = ta.a;
+    double* w = reinterpret_cast<double*>(smem);             // [J]
+    const int k = blockIdx.x, kg = a.k0 + k, lane = threadIdx.x, n = a.n, N = a.N, J = ta.J, M = ta.M;
+    const double* pot = ta.pot + (size_t)k * J;
+    double mx = -pm_inf();
+    for (int j = lane; j < J; j += 64) {
+        const double v = pot[j];
+        if (!pm_isnan(v) && v > mx) mx = v;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    const bool all_bad = !(mx > -pm_inf()) || mx == pm_inf();
+    for (int j = lane; j < J; j += 64) {
+        const double v = pot[j];
+        w[j] = all_bad ? 1.0 : (pm_isnan(v) ? 0.0 : pm_exp(v - mx));
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    double ssum = 0.0;
+    uint64_t total = 0;
+    for (int j = 0; j < J; ++j) {
+        ssum = ssum + w[j];
+        total += all_bad ? 1ull : (uint64_t)(w[j] * PM_CDF_SCALE);
+    }
+    const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_TWIST, PK_TWIST_DRAW_BLOCK, a.seed);
+    const uint64_t thr = pm_mulhi64(((uint64_t)x.y << 32) | x.x, total);
+    int jsel = J - 1;
+    uint64_t run = 0;
+    for (int j = 0; j < J; ++j) {
+        run += all_bad ? 1ull : (uint64_t)(w[j] * PM_CDF_SCALE);
+        if (run > thr) { jsel = j; break; }
+    }
+    const double logq = pot[jsel] - ((all_bad ? 0.0 : mx) + pm_log(ssum));
+    const int t = jsel / M;
+    int il = 0, rem = t;
+    while (rem >= n - 1 - il) { rem -= n - 1 - il; ++il; }
+    const int ir = il + 1 + rem;
+    ta.chosen[kg] = (double)jsel;
+    const int32_t* ro = ta.roots_ad + (size_t)kg * N;
+    const int32_t* co = ta.cnt_ad + (size_t)kg * N;
+    const double* rl = ta.rootll_ad + (size_t)kg * N;
+    double sum_rem = 0.0, fprior = 0.0;
+    int vminus = 0;
+    for (int i = n - 1; i >= 0; --i) {                       // remaining roots, descending slot order
+        if (i == il || i == ir) continue;
+        const int c = co[i];
+        sum_rem = sum_rem + rl[i];
+        fprior = fprior + (-a.ldf[c < a.ldf_n ? c : a.ldf_n]);
+        vminus += c - (c == 1 ? 1 : 0);
+    }
+    const int cnew = co[il] + co[ir];
+    fprior = fprior + (-a.ldf[cnew < a.ldf_n ? cnew : a.ldf_n]);
+    vminus += cnew - (cnew == 1 ? 1 : 0);
+    const double b_l = ta.tw_b[((size_t)k * J + jsel) * 2], b_r = ta.tw_b[((size_t)k * J + jsel) * 2 + 1];
+    ta.bl_r[k] = b_l;
+    ta.br_r[k] = b_r;
+    double lp = 0.0, rp = 0.0;
+    for (int j = 0; j <= a.r; ++j) {
+        const double hl = (j == a.r) ? b_l : a.bl[(size_t)j * a.Kloc + k];
+        const double hr = (j == a.r) ? b_r : a.br[(size_t)j * a.Kloc + k];
+        lp = lp + ((-a.lam_l) * hl + a.loglam_l);
+        rp = rp + ((-a.lam_r) * hr + a.loglam_r);
+    }
+    double* ax = a.aux + (size_t)k * PK_AUX;
+    ax[AUX_SUM_REM] = sum_rem;
+    ax[AUX_FPRIOR] = fprior;
+    ax[AUX_LPRIOR] = lp;
+    ax[AUX_RPRIOR] = rp;
+    ax[AUX_PAREN] = ((a.loglam_l - a.lam_l * b_l) + a.loglam_r) - a.lam_r * b_r;
+    ax[AUX_LOGV] = pm_log((double)vminus);
+    ax[AUX_Q] = logq;                                        // vncsmc.py:491 subtracts the normalised log-potential
+    a.child[k * 2] = ro[il];
+    a.child[k * 2 + 1] = ro[ir];
+    a.merges[((size_t)a.r * a.Kloc + k) * 2] = il;
+    a.merges[((size_t)a.r * a.Kloc + k) * 2 + 1] = ir;
+    const double* P = ta.tw_P + ((size_t)k * J + jsel) * 32;
+    for (int u = 0; u < 32; ++u) ta.Pmat_r[(size_t)k * 32 + u] = P[u];
+}
+
+__global__ void pk_twist_tables(const pk_twist_args ta) {
+    const pk_rank_args& a = ta.a;
+    const int kg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kg >= a.K) return;
+    const int n = a.n, N = a.N, t = (int)ta.chosen[kg] / ta.M;
+    int il = 0, rem = t;
+    while (rem >= n - 1 - il) { rem -= n - 1 - il; ++il; }
+    const int ir = il + 1 + rem;
+    const int32_t* ro = ta.roots_ad + (size_t)kg * N;
+    const int32_t* co = ta.cnt_ad + (size_t)kg * N;
+    const double* rl = ta.rootll_ad + (size_t)kg * N;
+    int p = 0;
+    for (int i = n - 1; i >= 0; --i) {
+        if (i == il || i == ir) continue;
+        a.roots_new[(size_t)kg * N + p] = ro[i];
+        a.cnt_new[(size_t)kg * N + p] = co[i];
+        a.rootll_new[(size_t)kg * N + p] = rl[i];
+        ++p;
+    }
+    a.roots_new[(size_t)kg * N + p] = N + a.r * a.K + kg;
+    a.cnt_new[(size_t)kg * N + p] = co[il] + co[ir];
+}
+
 // arithmetic probe
 __global__ void pk_math_probe(int op, const double* __restrict__ x, const double* __restrict__ y, int n,
                               double* __restrict__ out) {

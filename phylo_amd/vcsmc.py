@@ -170,9 +170,12 @@ class VCSMC:
             - right_branches_logprior
 
     # ---- the sweep ----------------------------------------------------------------------------------
-    def sample_phylogenies(self, seed=None, flags=_ffi.FLAGS_DEFAULT):
-        """vcsmc.py:406-451: the N-1 rank events on the device.  Sets the reference's attributes and
-        returns the ELBO (log Z-hat)."""
+    def sample_phylogenies(self, seed=None, flags=None):
+        """vcsmc.py:406-451 (vncsmc.py:505-560 with args.nested): the N-1 rank events on the device.  Sets
+        the reference's attributes and returns the ELBO (log Z-hat)."""
+        if flags is None:
+            flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if getattr(self.args, 'nested', False) else 0)
+        self._twisted = bool(flags & _ffi.TWISTING)
         seed = self.seed + self._sweeps if seed is None else int(seed)
         self._sweeps += 1
         out = self._context().sweep(seed, flags=flags, M=self.M)
@@ -203,8 +206,13 @@ class VCSMC:
             if r > 0:
                 idx = self.ancestors[r - 1]
                 jc, rec = jc[idx], rec[idx]
-            co, rem = rng.pair_order(K, N - r, self._last_seed, r)
-            assert np.array_equal(co, self.merges[r]), "host replay of the pair pick disagrees with the device"
+            if self._twisted:                      # chosen pair from the device; the rest in descending slot order
+                co = self.merges[r]
+                rem = np.array([[i for i in range(N - r - 1, -1, -1) if i != a and i != b] for a, b in co],
+                               dtype=np.int64).reshape(K, N - r - 2)
+            else:
+                co, rem = rng.pair_order(K, N - r, self._last_seed, r)
+                assert np.array_equal(co, self.merges[r]), "host replay of the pair pick disagrees with the device"
             new = np.array([a + '+' + b for a, b in gather_across_2d(jc, co)], dtype=object)
             jc = np.concatenate([gather_across_2d(jc, rem), new[:, None]], axis=1)
             rec = np.concatenate([gather_across_2d(rec, rem), gather_across_2d(rec, co).sum(axis=1)[:, None]], axis=1)

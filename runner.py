@@ -39,8 +39,6 @@ def main(argv=None):
     from phylo_amd.datasets import load_dataset
     from phylo_amd.vcsmc import VCSMC
     datadict = load_dataset(args.dataset)
-    if args.nested:
-        raise SystemExit("--nested/--twisting: the twisted proposal (vncsmc.py:295-416) is not available in this build")
     vcsmc = VCSMC(datadict, K=args.n_particles, args=args)
     return vcsmc.train(epochs=args.num_epoch, batch_size=args.batch_size, learning_rate=args.learning_rate,
                        memory_optimization=args.memory_optimization)

@@ -264,3 +264,39 @@ def test_error_behaviour(small):
     with pytest.raises(_ffi.PhyloError):
         ctx.set_model(O.jc_Q(), PI, np.zeros(8), np.ones(8))     # non-positive rate
     ctx.close()
+
+
+@pytest.mark.parametrize("dataset,K,M,jc", [
+    ('primate_data_wang', 16, 3, True),
+    ('primate_data', 48, 1, False),             # BASELINE config 2 shape: primate.p, GTR-init, twisting
+    ('primate_data', 20, 10, False),            # the reference's default M
+])
+def test_twisted_sweep_bit_exact_vs_oracle(dataset, K, M, jc):
+    """Row T: the twisted / nested proposal of vncsmc.py:295-416."""
+    g = load_dataset(dataset)['genome']
+    N = g.shape[0]
+    Q = O.jc_Q() if jc else O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    ctx = make_ctx(g, K, Q, jc=jc)
+    for seed in (0, 3):
+        out = ctx.sweep(seed, flags=_ffi.FLAGS_DEFAULT | _ffi.TWISTING, M=M)
+        ref = CO.sweep_twisted(g, Q, PI, lam, lam, K, M, seed, jc=jc, want_nodes=True)
+        np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
+        np.testing.assert_array_equal(out['merges'], ref['merges'])
+        assert (out['merges'][:, :, 0] < out['merges'][:, :, 1]).all()         # pairs r1 < r2
+        for key in ('left_branches', 'right_branches', 'log_likelihood', 'log_weights'):
+            assert_bit_equal(out[key], ref[key], key)
+        assert_bit_equal(out['logZ'], ref['logZ'], 'logZ')
+        assert_bit_equal(ctx.sweep_node(N - 2, K - 1), ref['nodes'][N - 2, K - 1], "node partial")
+    # the un-twisted sweep still works on the same context afterwards
+    a = ctx.sweep(1)
+    b = CO.sweep(g, Q, PI, lam, lam, K, 1, jc=jc)
+    assert_bit_equal(a['log_weights'], b['log_weights'], "plain sweep after a twisted one")
+    with pytest.raises(_ffi.PhyloError):
+        ctx.sweep(0, flags=_ffi.FLAGS_DEFAULT | _ffi.TWISTING, M=17)
+    ctx.close()
+    # independent NumPy oracle on a small case
+    if K <= 20:
+        ref2 = O.sweep_twisted(g, Q, PI, lam, lam, K, M, 3)
+        np.testing.assert_array_equal(out['ancestors'], ref2['ancestors'])
+        assert out['logZ'] == pytest.approx(ref2['logZ'], rel=1e-9)
