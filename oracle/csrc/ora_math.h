@@ -228,6 +228,31 @@ static inline void ora_jc69(double t, double* P) {
     for (int i = 0; i < 16; ++i) P[i] = (i % 5 == 0) ? d : o;
 }
 
+/* log of a running product (see DESIGN.md "Arithmetic contract"): mantissa product in [1,2) + integer
+ * exponent; factors that are not positive normal numbers are routed through ora_log into `extra`. */
+typedef struct { double p; int E; double extra; } ora_lp;
+static inline void ora_lp_init(ora_lp* a) { a->p = 1.0; a->E = 0; a->extra = 0.0; }
+static inline void ora_lp_mul(ora_lp* a, double x) {
+    uint64_t bx = ora_bits(x);
+    int ex = (int)((bx >> 52) & 0x7ff);
+    if ((bx >> 63) || ex == 0 || ex == 0x7ff) { a->extra = a->extra + ora_log(x); return; }
+    double mx = ora_dbl((bx & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    a->p = a->p * mx;
+    uint64_t bp = ora_bits(a->p);
+    a->E += (ex - 1023) + ((int)((bp >> 52) & 0x7ff) - 1023);
+    a->p = ora_dbl((bp & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+}
+static inline double ora_lp_finish(const ora_lp* a) {
+    double dE = (double)a->E;
+    return ((ora_log(a->p) + dE * 1.90821492927058770002e-10) + dE * 6.93147180369123816490e-01) + a->extra;
+}
+
+/* canonical sum of logs over sites: 256 log-product columns (site s multiplies into column s mod 256, in
+ * increasing s), each finished to a double, then the same tree as the canonical sum below. */
+typedef struct { ora_lp col[256]; } ora_canon_lp;
+static inline void ora_canon_lp_init(ora_canon_lp* c) { for (int i = 0; i < 256; ++i) ora_lp_init(&c->col[i]); }
+static inline void ora_canon_lp_mul(ora_canon_lp* c, long s, double x) { ora_lp_mul(&c->col[s & 255], x); }
+
 /* canonical sum: 256 columns (element s goes to column s mod 256, added in increasing s), then an
  * adjacent-pair tree inside each group of 64 columns, then the four groups left to right. */
 typedef struct { double col[256]; } ora_canon;
@@ -238,5 +263,10 @@ static inline double ora_canon_total(ora_canon* c) {
         for (int st = 1; st < 64; st <<= 1)
             for (int i = 0; i < 64; i += 2 * st) c->col[g * 64 + i] = c->col[g * 64 + i] + c->col[g * 64 + i + st];
     return ((c->col[0] + c->col[64]) + c->col[128]) + c->col[192];
+}
+static inline double ora_canon_lp_total(ora_canon_lp* c) {
+    ora_canon t;
+    for (int i = 0; i < 256; ++i) t.col[i] = ora_lp_finish(&c->col[i]);
+    return ora_canon_total(&t);
 }
 #endif

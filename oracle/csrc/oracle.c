@@ -91,10 +91,10 @@ static inline double site_lik(const double* pi, const double* x) {
 
 /* sum_s log(pi . x[s]) in the canonical order */
 static double row_loglik(const double* pi, const double* x, int S) {
-    ora_canon c;
-    ora_canon_init(&c);
-    for (int s = 0; s < S; ++s) ora_canon_add(&c, s, ora_log(site_lik(pi, x + (size_t)s * 4)));
-    return ora_canon_total(&c);
+    ora_canon_lp c;
+    ora_canon_lp_init(&c);
+    for (int s = 0; s < S; ++s) ora_canon_lp_mul(&c, s, site_lik(pi, x + (size_t)s * 4));
+    return ora_canon_lp_total(&c);
 }
 
 /* VCSMC.broadcast_conditional_likelihood_K, vcsmc.py:180-188 */

@@ -41,6 +41,8 @@ struct phylo_ctx {
     // model + leaves
     double *d_Q = nullptr, *d_pi = nullptr, *d_lam_l = nullptr, *d_lam_r = nullptr, *d_ldf = nullptr;
     double* d_leaves = nullptr;          // [N][S][4]
+    uint8_t* d_leaf_codes = nullptr;     // [N][S]; in use only when every leaf row is one-hot or all-ones
+    bool leaves_coded = false;
     // sweep state
     double* d_pool = nullptr;            // [(N-1)][Kloc][S][4]
     double* d_nodell = nullptr;          // [N + (N-1)*K]
@@ -244,6 +246,7 @@ int phylo_create(const int* device_ids, int n_gpus, int K, int N, int S, int A, 
         if ((rc = dalloc(c, &c->d_lam_r, (size_t)N)) != PHYLO_OK) break;
         if ((rc = dalloc(c, &c->d_ldf, (size_t)N + 1)) != PHYLO_OK) break;
         if ((rc = dalloc(c, &c->d_leaves, (size_t)N * S * 4)) != PHYLO_OK) break;
+        if ((rc = dalloc(c, &c->d_leaf_codes, (size_t)N * S)) != PHYLO_OK) break;
         if ((rc = alloc_sweep_state(c)) != PHYLO_OK) break;
         // table of log (2 max(c,2) - 3)!! by leaf count c = 0..N
         c->h_ldf.resize((size_t)N + 1);
@@ -265,7 +268,7 @@ int phylo_destroy(phylo_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     phylo_comm_destroy(&c->comm);
     free_sweep_state(c);
-    void* ptrs[] = {c->d_Q, c->d_pi, c->d_lam_l, c->d_lam_r, c->d_ldf, c->d_leaves};
+    void* ptrs[] = {c->d_Q, c->d_pi, c->d_lam_l, c->d_lam_r, c->d_ldf, c->d_leaves, c->d_leaf_codes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& b : c->scratch)
@@ -282,6 +285,25 @@ int phylo_set_leaves(phylo_ctx* c, const double* genome) {
     CHK(bind(c));
     if (!genome) return fail(c, PHYLO_EINVAL, "genome_NxSxA is NULL");
     HIPCHK(c, hipMemcpyAsync(c->d_leaves, genome, (size_t)c->N * c->S * 4 * 8, hipMemcpyHostToDevice, c->stream));
+    // one-hot / all-ones rows (the reference's encoding, runner.py:83-96) also get a 1-byte code per site
+    {
+        const size_t rows = (size_t)c->N * c->S;
+        std::vector<uint8_t> codes(rows);
+        bool ok = !getenv("PHYLO_NO_LEAF_CODES");
+        for (size_t i = 0; i < rows && ok; ++i) {
+            const double* x = genome + i * 4;
+            int ones = 0, zeros = 0, last = 0;
+            for (int j = 0; j < 4; ++j) {
+                if (pm_bits(x[j]) == pm_bits(1.0)) { ++ones; last = j; }
+                else if (pm_bits(x[j]) == 0) ++zeros;
+            }
+            if (ones == 1 && zeros == 3) codes[i] = (uint8_t)last;
+            else if (ones == 4) codes[i] = 4;
+            else ok = false;
+        }
+        c->leaves_coded = ok;
+        if (ok) HIPCHK(c, hipMemcpy(c->d_leaf_codes, codes.data(), rows, hipMemcpyHostToDevice));
+    }
     c->have_leaves = true;
     CHK(refresh_leaf_ll(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -551,6 +573,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         b.loglam_l = pm_log(b.lam_l); b.loglam_r = pm_log(b.lam_r);
         b.ll_tilde0 = ll_tilde0;
         b.leaves = c->d_leaves; b.pool = c->d_pool; b.pool_ptrs = c->d_pool_ptrs;
+        b.leaf_codes = c->leaves_coded ? c->d_leaf_codes : nullptr;
         b.Pmat = c->d_Pmat + (size_t)r * Kl * 32;
         b.pi = c->d_pi;
         b.logw_r = c->d_logw + (size_t)r * K;
@@ -570,7 +593,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
             CHK(launch_check(c, "pk_twist_adopt"));
             hipLaunchKernelGGL(pk_twist_draws, dim3(cdiv(2L * Kl * ta.J, 64)), dim3(64), 0, c->stream, ta, (const double*)c->d_Q, c->jc);
             CHK(launch_check(c, "pk_twist_draws"));
-            hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((size_t)Kl * (ta.J / M))), dim3(PK_COLS), 0, c->stream, ta);
+            hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((size_t)Kl * (N - r - 1))), dim3(PK_COLS), 0, c->stream, ta);
             CHK(launch_check(c, "pk_twist_potentials"));
             hipLaunchKernelGGL(pk_twist_choose, dim3(Kl), dim3(64), (size_t)ta.J * 8, c->stream, ta);
             CHK(launch_check(c, "pk_twist_choose"));

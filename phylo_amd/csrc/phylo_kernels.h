@@ -14,7 +14,9 @@
 enum { AUX_SUM_REM = 0, AUX_FPRIOR, AUX_LPRIOR, AUX_RPRIOR, AUX_LL_TILDE, AUX_PAREN, AUX_LOGV, AUX_Q };
 
 // ------------------------------------------------------------------------------------------------
-// canonical sum over the 256 columns of a workgroup: adjacent-pair tree inside each 64-lane wave
+// canonical sum over sites: element s belongs to column s mod 256; a column's value is the log of the
+// running product of its elements in increasing s (pm_lp); the 256 column values are then added by the tree
+// below.  Canonical sum over the 256 columns of a workgroup: adjacent-pair tree inside each 64-lane wave
 // (xor butterfly 1,2,...,32: a+b == b+a bitwise, so every lane ends with the same value), then the four
 // wave totals left to right.  oracle/csrc/oracle.c mirrors exactly this tree.
 // ------------------------------------------------------------------------------------------------
@@ -27,9 +29,15 @@ __device__ __forceinline__ double pk_block_canon_sum(double col, double* sh4) {
     return ((sh4[0] + sh4[1]) + sh4[2]) + sh4[3];
 }
 
+// Partial-likelihood rows always live in global memory (leaves, this rank's pool or a peer's mapped pool), but
+// a pool base fetched from the pointer table is a generic pointer to the compiler, which then emits flat_load
+// (uncounted waits, no software pipelining).  Loads go through an explicit global-address-space pointer.
+typedef double pk_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const pk_d2 pk_gd2c;
+__device__ __forceinline__ pk_d2 pk_gload2(const double* p) { return *(pk_gd2c*)p; }
+
 __device__ __forceinline__ void pk_load4(const double* __restrict__ p, double* v) {
-    const double2 a = reinterpret_cast<const double2*>(p)[0];
-    const double2 b = reinterpret_cast<const double2*>(p)[1];
+    const pk_d2 a = pk_gload2(p), b = pk_gload2(p + 2);
     v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 
@@ -40,7 +48,6 @@ __device__ __forceinline__ void pk_store4(double* __restrict__ p, const double* 
 
 // streaming (non-temporal) form: the new node is read again only by the few particles that survive the next
 // resampling, so it should not displace the leaves and live ancestors from L2
-typedef double pk_d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void pk_store4_nt(double* __restrict__ p, const double* v) {
     pk_d2 a = {v[0], v[1]}, b = {v[2], v[3]};
     __builtin_nontemporal_store(a, reinterpret_cast<pk_d2*>(p));
@@ -118,13 +125,13 @@ __global__ __launch_bounds__(PK_COLS) void pk_row_loglik(const double* __restric
     __shared__ double sh4[4];
     const double* row = x + (size_t)blockIdx.x * S * 4;
     double pi[4] = {pi4[0], pi4[1], pi4[2], pi4[3]};
-    double col = 0.0;
+    pm_lp col = pm_lp_init();
     for (int s = threadIdx.x; s < S; s += PK_COLS) {
         double v[4];
         pk_load4(row + (size_t)s * 4, v);
-        col = col + pm_log(pk_site_lik(pi, v));
+        pm_lp_mul(col, pk_site_lik(pi, v));
     }
-    const double tot = pk_block_canon_sum(col, sh4);
+    const double tot = pk_block_canon_sum(pm_lp_finish(col), sh4);
     if (threadIdx.x == 0) out[blockIdx.x] = tot;
 }
 
@@ -440,6 +447,7 @@ struct pk_rank_args {
     const double* bl; const double* br;                   // [R][Kloc]
     double lam_l, lam_r, loglam_l, loglam_r, ll_tilde0;
     const double* leaves;                                 // [N][S][4]
+    const uint8_t* leaf_codes;                            // [N][S] 0..3 one-hot state, 4 all-ones; NULL if some row is neither
     double* pool;                                         // [(N-1)][Kloc][S][4]: this rank's nodes
     const double* const* pool_ptrs;                       // [world]: every rank's pool as mapped in this process
     const double* Pmat;                                   // [Kloc][32] of this rank
@@ -675,12 +683,109 @@ __device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int 
     return a.pool_ptrs[owner] + ((size_t)rho * a.Kloc + (kap - owner * a.Kloc)) * node_sz;
 }
 
+// (L . P)[2h + c] for a leaf row given by its code: a one-hot row selects an entry of my P columns, an
+// all-ones row (gap, runner.py:95-96) their fma-chain sum -- exactly what the generic chain returns for
+// those rows, without reading the 32-byte row.
+__device__ __forceinline__ double pk_sel5(int code, double p0, double p1, double p2, double p3, double g) {
+    double x = p0;
+    x = code == 1 ? p1 : x;
+    x = code == 2 ? p2 : x;
+    x = code == 3 ? p3 : x;
+    x = code == 4 ? g : x;
+    return x;
+}
+
+template <bool CL, bool CR>
+__device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, const double* Lp, const double* Rp,
+                                              const uint8_t* Lc, const uint8_t* Rc, double* out,
+                                              const double (&Plc)[4][2], const double (&Prc)[4][2], pm_lp& col, int p, int h) {
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    const int S = a.S;
+    double gl[2], gr[2];                            // chain over an all-ones row
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        gl[c] = pm_fma(1.0, Plc[3][c], pm_fma(1.0, Plc[2][c], pm_fma(1.0, Plc[1][c], 1.0 * Plc[0][c])));
+        gr[c] = pm_fma(1.0, Prc[3][c], pm_fma(1.0, Prc[2][c], pm_fma(1.0, Prc[1][c], 1.0 * Prc[0][c])));
+    }
+    // software pipeline: the next step's rows (or codes) are fetched before this step is computed
+    pk_d2 nla = {0, 0}, nra = {0, 0}, nlb = {0, 0}, nrb = {0, 0};
+    int ncla = 0, ncra = 0, nclb = 0, ncrb = 0;
+    if (p < S) {
+        if (CL) ncla = Lc[p]; else nla = pk_gload2(Lp + (size_t)p * 4);
+        if (CR) ncra = Rc[p]; else nra = pk_gload2(Rp + (size_t)p * 4);
+    }
+    if (p + 128 < S) {
+        if (CL) nclb = Lc[p + 128]; else nlb = pk_gload2(Lp + (size_t)(p + 128) * 4);
+        if (CR) ncrb = Rc[p + 128]; else nrb = pk_gload2(Rp + (size_t)(p + 128) * 4);
+    }
+    const int nq = (S + 255) >> 8;
+    for (int q = 0; q < nq; ++q) {
+        const int sa = p + 256 * q, sb = sa + 128;
+        const bool va = sa < S, vb = sb < S;
+        const pk_d2 la = nla, ra = nra, lb = nlb, rb = nrb;
+        const int cla = ncla, cra = ncra, clb = nclb, crb = ncrb;
+        if (sa + 256 < S) {
+            if (CL) ncla = Lc[sa + 256]; else nla = pk_gload2(Lp + (size_t)(sa + 256) * 4);
+            if (CR) ncra = Rc[sa + 256]; else nra = pk_gload2(Rp + (size_t)(sa + 256) * 4);
+        }
+        if (sb + 256 < S) {
+            if (CL) nclb = Lc[sb + 256]; else nlb = pk_gload2(Lp + (size_t)(sb + 256) * 4);
+            if (CR) ncrb = Rc[sb + 256]; else nrb = pk_gload2(Rp + (size_t)(sb + 256) * 4);
+        }
+        double lik[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const pk_d2 l2 = t ? lb : la, r2 = t ? rb : ra;
+            const int cl = t ? clb : cla, cr = t ? crb : cra;
+            double lp[2], rp[2];
+            if (CL) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) lp[c] = pk_sel5(cl, Plc[0][c], Plc[1][c], Plc[2][c], Plc[3][c], gl[c]);
+            } else {
+                const double L[4] = {pk_dpp_even(l2.x), pk_dpp_even(l2.y), pk_dpp_odd(l2.x), pk_dpp_odd(l2.y)};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    double v = L[0] * Plc[0][c];
+                    v = pm_fma(L[1], Plc[1][c], v);
+                    v = pm_fma(L[2], Plc[2][c], v);
+                    lp[c] = pm_fma(L[3], Plc[3][c], v);
+                }
+            }
+            if (CR) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) rp[c] = pk_sel5(cr, Prc[0][c], Prc[1][c], Prc[2][c], Prc[3][c], gr[c]);
+            } else {
+                const double R[4] = {pk_dpp_even(r2.x), pk_dpp_even(r2.y), pk_dpp_odd(r2.x), pk_dpp_odd(r2.y)};
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    double v = R[0] * Prc[0][c];
+                    v = pm_fma(R[1], Prc[1][c], v);
+                    v = pm_fma(R[2], Prc[2][c], v);
+                    rp[c] = pm_fma(R[3], Prc[3][c], v);
+                }
+            }
+            const double o[2] = {lp[0] * rp[0], lp[1] * rp[1]};
+            if (t ? vb : va) {
+                const pk_d2 ov = {o[0], o[1]};
+                __builtin_nontemporal_store(ov, reinterpret_cast<pk_d2*>(out + (size_t)(t ? sb : sa) * 4));
+            }
+            const double f[4] = {pk_dpp_even(o[0]), pk_dpp_even(o[1]), pk_dpp_odd(o[0]), pk_dpp_odd(o[1])};
+            lik[t] = pk_site_lik(pi, f);
+        }
+        if (h ? vb : va) pm_lp_mul(col, h ? lik[1] : lik[0]);
+    }
+}
+
 __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a) {
     __shared__ double cols[PK_COLS];
     __shared__ double sh4[4];
     const int k = blockIdx.x, kg = a.k0 + k, tid = threadIdx.x, p = tid >> 1, h = tid & 1;
-    const double* Lp = pk_node_ptr(a, a.child[k * 2]) + 2 * h;
-    const double* Rp = pk_node_ptr(a, a.child[k * 2 + 1]) + 2 * h;
+    const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
+    const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // workgroup-uniform
+    const double* Lp = pk_node_ptr(a, cl) + 2 * h;
+    const double* Rp = pk_node_ptr(a, cr) + 2 * h;
+    const uint8_t* Lc = a.leaf_codes + (codedL ? (size_t)cl * a.S : 0);
+    const uint8_t* Rc = a.leaf_codes + (codedR ? (size_t)cr * a.S : 0);
     double* out = a.pool + ((size_t)a.r * a.Kloc + k) * (size_t)a.S * 4 + 2 * h;
     const double* P = a.Pmat + (size_t)k * 32 + 2 * h;
     double Plc[4][2], Prc[4][2];                    // my two columns (states 2h, 2h+1) of P_l and P_r
@@ -690,48 +795,15 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a
         const pk_d2 y = *reinterpret_cast<const pk_d2*>(P + 16 + i * 4);
         Plc[i][0] = x.x; Plc[i][1] = x.y; Prc[i][0] = y.x; Prc[i][1] = y.y;
     }
-    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
-    const int S = a.S;
-    double col = 0.0;
-    pk_d2 nla = {0, 0}, nra = {0, 0}, nlb = {0, 0}, nrb = {0, 0};     // software pipeline: next step's rows
-    if (p < S) { nla = *reinterpret_cast<const pk_d2*>(Lp + (size_t)p * 4); nra = *reinterpret_cast<const pk_d2*>(Rp + (size_t)p * 4); }
-    if (p + 128 < S) { nlb = *reinterpret_cast<const pk_d2*>(Lp + (size_t)(p + 128) * 4); nrb = *reinterpret_cast<const pk_d2*>(Rp + (size_t)(p + 128) * 4); }
-    const int nq = (S + 255) >> 8;
-    for (int q = 0; q < nq; ++q) {
-        const int sa = p + 256 * q, sb = sa + 128;
-        const bool va = sa < S, vb = sb < S;
-        const pk_d2 la = nla, ra = nra, lb = nlb, rb = nrb;
-        if (sa + 256 < S) { nla = *reinterpret_cast<const pk_d2*>(Lp + (size_t)(sa + 256) * 4); nra = *reinterpret_cast<const pk_d2*>(Rp + (size_t)(sa + 256) * 4); }
-        if (sb + 256 < S) { nlb = *reinterpret_cast<const pk_d2*>(Lp + (size_t)(sb + 256) * 4); nrb = *reinterpret_cast<const pk_d2*>(Rp + (size_t)(sb + 256) * 4); }
-        double lik[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const pk_d2 l2 = t ? lb : la, r2 = t ? rb : ra;
-            const double L[4] = {pk_dpp_even(l2.x), pk_dpp_even(l2.y), pk_dpp_odd(l2.x), pk_dpp_odd(l2.y)};
-            const double R[4] = {pk_dpp_even(r2.x), pk_dpp_even(r2.y), pk_dpp_odd(r2.x), pk_dpp_odd(r2.y)};
-            double o[2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                double lp = L[0] * Plc[0][c];
-                lp = pm_fma(L[1], Plc[1][c], lp);
-                lp = pm_fma(L[2], Plc[2][c], lp);
-                lp = pm_fma(L[3], Plc[3][c], lp);
-                double rp = R[0] * Prc[0][c];
-                rp = pm_fma(R[1], Prc[1][c], rp);
-                rp = pm_fma(R[2], Prc[2][c], rp);
-                rp = pm_fma(R[3], Prc[3][c], rp);
-                o[c] = lp * rp;
-            }
-            if (t ? vb : va) {
-                const pk_d2 ov = {o[0], o[1]};
-                __builtin_nontemporal_store(ov, reinterpret_cast<pk_d2*>(out + (size_t)(t ? sb : sa) * 4));
-            }
-            const double f[4] = {pk_dpp_even(o[0]), pk_dpp_even(o[1]), pk_dpp_odd(o[0]), pk_dpp_odd(o[1])};
-            lik[t] = pk_site_lik(pi, f);
-        }
-        if (h ? vb : va) col = col + pm_log(h ? lik[1] : lik[0]);
+    pm_lp col = pm_lp_init();
+    if (codedL) {
+        if (codedR) pk_merge_body<true, true>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, col, p, h);
+        else pk_merge_body<true, false>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, col, p, h);
+    } else {
+        if (codedR) pk_merge_body<false, true>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, col, p, h);
+        else pk_merge_body<false, false>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, col, p, h);
     }
-    cols[p + 128 * h] = col;                        // lane (p, h) owns canonical column p + 128 h
+    cols[p + 128 * h] = pm_lp_finish(col);          // lane (p, h) owns canonical column p + 128 h
     __syncthreads();
     const double tot = pk_block_canon_sum(cols[tid], sh4);
     if (tid == 0) {
@@ -821,52 +893,75 @@ __global__ __launch_bounds__(64) void pk_twist_draws(const pk_twist_args ta, con
     for (int u = 0; u < 16; ++u) out[u] = p[u];
 }
 
-// one workgroup per (local particle, pair): rows of the two roots are read once per site step and reused for
-// the M sub-samples; nothing is stored but the M potentials.
-__global__ __launch_bounds__(PK_COLS) void pk_twist_potentials(const pk_twist_args ta) {
-    __shared__ double sh4[4];
+// One workgroup per (local particle, left root r1): all pairs (r1, r2 > r1) x M sub-samples.  Thread c owns
+// canonical column c (sites c, c+256, ...) of every pair; column sums go to LDS and each wave then runs the
+// canonical tree for whole (pair, sub-sample) rows, so there is one barrier per workgroup instead of two per
+// potential.  Nothing is stored but the potentials.  fp64-VALU bound (about 80 flops per particle-site-pair).
+// force a wave-uniform value into scalar registers (the compiler keeps uniform loads in VGPRs once the
+// kernel has stored to global memory)
+__device__ __forceinline__ double pk_uniform(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+#define PK_TWIST_LDS_ROWS 8             // (pair, sub-sample) rows reduced per pass
+__global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist_args ta) {
+    __shared__ double cols[PK_TWIST_LDS_ROWS][PK_COLS];
     const pk_rank_args& a = ta.a;
-    const int n = a.n, M = ta.M, npairs = n * (n - 1) / 2;
-    const int k = blockIdx.x / npairs, t = blockIdx.x - k * npairs, kg = a.k0 + k;
-    int r1 = 0, rem = t;                             // decode the lexicographic pair index
-    while (rem >= n - 1 - r1) { rem -= n - 1 - r1; ++r1; }
-    const int r2 = r1 + 1 + rem;
+    const int n = a.n, M = ta.M, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int k = blockIdx.x / (n - 1), r1 = blockIdx.x - k * (n - 1), kg = a.k0 + k;
     const int32_t* ro = ta.roots_ad + (size_t)kg * a.N;
+    const int32_t* co = ta.cnt_ad + (size_t)kg * a.N;
+    const double* rl = ta.rootll_ad + (size_t)kg * a.N;
     const double* Lp = pk_node_ptr(a, ro[r1]);
-    const double* Rp = pk_node_ptr(a, ro[r2]);
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
-    const double* Pbase = ta.tw_P + ((size_t)k * ta.J + (size_t)t * M) * 32;
-    double acc[PK_TWIST_MAX_M];
+    // pair index of (r1, r1+1): sum_{i<r1} (n-1-i)
+    const int t0 = r1 * (n - 1) - r1 * (r1 - 1) / 2;
+    const int nrows = (n - 1 - r1) * M;                  // rows of this workgroup: (r2 - r1 - 1) * M + m
+    for (int base = 0; base < nrows; base += PK_TWIST_LDS_ROWS) {
+        const int cnt = nrows - base < PK_TWIST_LDS_ROWS ? nrows - base : PK_TWIST_LDS_ROWS;
+        for (int q = 0; q < cnt; ++q) {
+            const int row = base + q, r2 = r1 + 1 + row / M, m = row - (row / M) * M;
+            const double* Rp = pk_node_ptr(a, ro[r2]);
+            const double* P = ta.tw_P + ((size_t)k * ta.J + (size_t)(t0 + r2 - r1 - 1) * M + m) * 32;
+            double Pl[16], Pr[16];
 #pragma unroll
-    for (int m = 0; m < PK_TWIST_MAX_M; ++m) acc[m] = 0.0;
-    for (int s = threadIdx.x; s < a.S; s += PK_COLS) {
-        double Lv[4], Rv[4];
-        pk_load4(Lp + (size_t)s * 4, Lv);
-        pk_load4(Rp + (size_t)s * 4, Rv);
+            for (int u = 0; u < 16; ++u) { Pl[u] = pk_uniform(P[u]); Pr[u] = P[16 + u]; }   // P_l in SGPRs, P_r in VGPRs
+            pm_lp col = pm_lp_init();
+            double Ln[4], Rn[4];                                 // software pipeline: next step's rows
+            if (tid < a.S) { pk_load4(Lp + (size_t)tid * 4, Ln); pk_load4(Rp + (size_t)tid * 4, Rn); }
+            for (int s = tid; s < a.S; s += PK_COLS) {
+                double Lv[4], Rv[4], o[4];
 #pragma unroll
-        for (int m = 0; m < PK_TWIST_MAX_M; ++m) {
-            if (m < M) {
-                const double* P = Pbase + m * 32;
-                double o[4];
-                pk_merge_site(Lv, Rv, P, P + 16, o);
-                acc[m] = acc[m] + pm_log(pk_site_lik(pi, o));
+                for (int u = 0; u < 4; ++u) { Lv[u] = Ln[u]; Rv[u] = Rn[u]; }
+                if (s + PK_COLS < a.S) { pk_load4(Lp + (size_t)(s + PK_COLS) * 4, Ln); pk_load4(Rp + (size_t)(s + PK_COLS) * 4, Rn); }
+                pk_merge_site(Lv, Rv, Pl, Pr, o);
+                pm_lp_mul(col, pk_site_lik(pi, o));
             }
+            cols[q][tid] = pm_lp_finish(col);
         }
-    }
-    const int c1 = ta.cnt_ad[(size_t)kg * a.N + r1], c2 = ta.cnt_ad[(size_t)kg * a.N + r2];
-    const double l1 = ta.rootll_ad[(size_t)kg * a.N + r1], l2 = ta.rootll_ad[(size_t)kg * a.N + r2];
+        __syncthreads();
+        for (int q = wv; q < cnt; q += 4) {               // canonical tree of one row per wave
+            double g[4];
 #pragma unroll
-    for (int m = 0; m < PK_TWIST_MAX_M; ++m) {
-        if (m < M) {
-            const double tot = pk_block_canon_sum(acc[m], sh4);
-            if (threadIdx.x == 0) {
-                const int c12 = c1 + c2;
+            for (int u = 0; u < 4; ++u) {
+                double v = cols[q][lane + 64 * u];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+                g[u] = v;
+            }
+            if (lane == 0) {
+                const double tot = ((g[0] + g[1]) + g[2]) + g[3];
+                const int row = base + q, r2 = r1 + 1 + row / M, m = row - (row / M) * M;
+                const int c1 = co[r1], c2 = co[r2], c12 = c1 + c2;
                 double jp = tot + (-a.ldf[c12 < a.ldf_n ? c12 : a.ldf_n]);
-                jp = jp - (l1 + (-a.ldf[c1 < a.ldf_n ? c1 : a.ldf_n]));
-                jp = jp - (l2 + (-a.ldf[c2 < a.ldf_n ? c2 : a.ldf_n]));
-                ta.pot[(size_t)k * ta.J + (size_t)t * M + m] = jp;
+                jp = jp - (rl[r1] + (-a.ldf[c1 < a.ldf_n ? c1 : a.ldf_n]));
+                jp = jp - (rl[r2] + (-a.ldf[c2 < a.ldf_n ? c2 : a.ldf_n]));
+                ta.pot[(size_t)k * ta.J + (size_t)(t0 + r2 - r1 - 1) * M + m] = jp;
             }
         }
+        __syncthreads();
     }
 }
 
