@@ -683,30 +683,25 @@ __device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int 
     return a.pool_ptrs[owner] + ((size_t)rho * a.Kloc + (kap - owner * a.Kloc)) * node_sz;
 }
 
-// (L . P)[2h + c] for a leaf row given by its code: a one-hot row selects an entry of my P columns, an
-// all-ones row (gap, runner.py:95-96) their fma-chain sum -- exactly what the generic chain returns for
-// those rows, without reading the 32-byte row.
-__device__ __forceinline__ double pk_sel5(int code, double p0, double p1, double p2, double p3, double g) {
-    double x = p0;
-    x = code == 1 ? p1 : x;
-    x = code == 2 ? p2 : x;
-    x = code == 3 ? p3 : x;
-    x = code == 4 ? g : x;
-    return x;
+// Leaf children whose rows are one-hot / all-ones (the reference's encoding, runner.py:83-96) are read as a
+// 1-byte code per site; (row . P) is then a 16-byte LDS lookup -- bit-identical to the generic chain on
+// those rows, without moving the 32-byte row.
+// table[code][j] = (leaf row of that code . P)[j]: rows 0..3 are the rows of P, row 4 the chain over an all-ones row
+__device__ __forceinline__ void pk_build_leaf_table(const double* __restrict__ P /*16, uniform*/, double (*tab)[4], int t) {
+    if (t < 16) tab[t >> 2][t & 3] = P[t];
+    else if (t < 20) {
+        const int j = t - 16;
+        tab[4][j] = pm_fma(1.0, P[12 + j], pm_fma(1.0, P[8 + j], pm_fma(1.0, P[4 + j], 1.0 * P[j])));
+    }
 }
 
 template <bool CL, bool CR>
 __device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, const double* Lp, const double* Rp,
                                               const uint8_t* Lc, const uint8_t* Rc, double* out,
-                                              const double (&Plc)[4][2], const double (&Prc)[4][2], pm_lp& col, int p, int h) {
+                                              const double (&Plc)[4][2], const double (&Prc)[4][2],
+                                              const double (*tabL)[4], const double (*tabR)[4], pm_lp& col, int p, int h) {
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     const int S = a.S;
-    double gl[2], gr[2];                            // chain over an all-ones row
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        gl[c] = pm_fma(1.0, Plc[3][c], pm_fma(1.0, Plc[2][c], pm_fma(1.0, Plc[1][c], 1.0 * Plc[0][c])));
-        gr[c] = pm_fma(1.0, Prc[3][c], pm_fma(1.0, Prc[2][c], pm_fma(1.0, Prc[1][c], 1.0 * Prc[0][c])));
-    }
     // software pipeline: the next step's rows (or codes) are fetched before this step is computed
     pk_d2 nla = {0, 0}, nra = {0, 0}, nlb = {0, 0}, nrb = {0, 0};
     int ncla = 0, ncra = 0, nclb = 0, ncrb = 0;
@@ -739,8 +734,8 @@ __device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, const doubl
             const int cl = t ? clb : cla, cr = t ? crb : cra;
             double lp[2], rp[2];
             if (CL) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) lp[c] = pk_sel5(cl, Plc[0][c], Plc[1][c], Plc[2][c], Plc[3][c], gl[c]);
+                const pk_d2 v = *reinterpret_cast<const pk_d2*>(&tabL[cl][2 * h]);      // one ds_read_b128
+                lp[0] = v.x; lp[1] = v.y;
             } else {
                 const double L[4] = {pk_dpp_even(l2.x), pk_dpp_even(l2.y), pk_dpp_odd(l2.x), pk_dpp_odd(l2.y)};
 #pragma unroll
@@ -752,8 +747,8 @@ __device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, const doubl
                 }
             }
             if (CR) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) rp[c] = pk_sel5(cr, Prc[0][c], Prc[1][c], Prc[2][c], Prc[3][c], gr[c]);
+                const pk_d2 v = *reinterpret_cast<const pk_d2*>(&tabR[cr][2 * h]);
+                rp[0] = v.x; rp[1] = v.y;
             } else {
                 const double R[4] = {pk_dpp_even(r2.x), pk_dpp_even(r2.y), pk_dpp_odd(r2.x), pk_dpp_odd(r2.y)};
 #pragma unroll
@@ -779,6 +774,7 @@ __device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, const doubl
 __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a) {
     __shared__ double cols[PK_COLS];
     __shared__ double sh4[4];
+    __shared__ __attribute__((aligned(16))) double tabL[5][4], tabR[5][4];
     const int k = blockIdx.x, kg = a.k0 + k, tid = threadIdx.x, p = tid >> 1, h = tid & 1;
     const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
     const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // workgroup-uniform
@@ -795,13 +791,19 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a
         const pk_d2 y = *reinterpret_cast<const pk_d2*>(P + 16 + i * 4);
         Plc[i][0] = x.x; Plc[i][1] = x.y; Prc[i][0] = y.x; Prc[i][1] = y.y;
     }
+    if (codedL || codedR) {
+        const double* Pu = a.Pmat + (size_t)k * 32;
+        if (tid < 32) pk_build_leaf_table(Pu, tabL, tid);
+        else if (tid < 64) pk_build_leaf_table(Pu + 16, tabR, tid - 32);
+        __syncthreads();
+    }
     pm_lp col = pm_lp_init();
     if (codedL) {
-        if (codedR) pk_merge_body<true, true>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, col, p, h);
-        else pk_merge_body<true, false>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, col, p, h);
+        if (codedR) pk_merge_body<true, true>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);
+        else pk_merge_body<true, false>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);
     } else {
-        if (codedR) pk_merge_body<false, true>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, col, p, h);
-        else pk_merge_body<false, false>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, col, p, h);
+        if (codedR) pk_merge_body<false, true>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);
+        else pk_merge_body<false, false>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);
     }
     cols[p + 128 * h] = pm_lp_finish(col);          // lane (p, h) owns canonical column p + 128 h
     __syncthreads();
@@ -893,6 +895,59 @@ __global__ __launch_bounds__(64) void pk_twist_draws(const pk_twist_args ta, con
     for (int u = 0; u < 16; ++u) out[u] = p[u];
 }
 
+// one (pair, sub-sample) row of potentials for my canonical column: sites tid, tid + 256, ...
+template <bool CL, bool CR>
+__device__ __forceinline__ void pk_twist_row(const pk_rank_args& a, const double* Lp, const double* Rp, const uint8_t* Lc,
+                                             const uint8_t* Rc, const double (&Pl)[16], const double (&Pr)[16],
+                                             const double (*tabL)[4], const double (*tabR)[4],
+                                             const double (&pi)[4], pm_lp& col) {
+    const int tid = threadIdx.x, S = a.S;
+    double Ln[4] = {0, 0, 0, 0}, Rn[4] = {0, 0, 0, 0};                 // software pipeline: next step's rows / codes
+    int cln = 0, crn = 0;
+    if (tid < S) {
+        if (CL) cln = Lc[tid]; else pk_load4(Lp + (size_t)tid * 4, Ln);
+        if (CR) crn = Rc[tid]; else pk_load4(Rp + (size_t)tid * 4, Rn);
+    }
+    for (int s = tid; s < S; s += PK_COLS) {
+        double Lv[4], Rv[4], o[4];
+        const int cl = cln, cr = crn;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { Lv[u] = Ln[u]; Rv[u] = Rn[u]; }
+        if (s + PK_COLS < S) {
+            if (CL) cln = Lc[s + PK_COLS]; else pk_load4(Lp + (size_t)(s + PK_COLS) * 4, Ln);
+            if (CR) crn = Rc[s + PK_COLS]; else pk_load4(Rp + (size_t)(s + PK_COLS) * 4, Rn);
+        }
+        double lpv[4], rpv[4];
+        if (CL) {
+            const pk_d2 x = *reinterpret_cast<const pk_d2*>(&tabL[cl][0]), y = *reinterpret_cast<const pk_d2*>(&tabL[cl][2]);
+            lpv[0] = x.x; lpv[1] = x.y; lpv[2] = y.x; lpv[3] = y.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double v = Lv[0] * Pl[j];
+                v = pm_fma(Lv[1], Pl[4 + j], v);
+                v = pm_fma(Lv[2], Pl[8 + j], v);
+                lpv[j] = pm_fma(Lv[3], Pl[12 + j], v);
+            }
+        }
+        if (CR) {
+            const pk_d2 x = *reinterpret_cast<const pk_d2*>(&tabR[cr][0]), y = *reinterpret_cast<const pk_d2*>(&tabR[cr][2]);
+            rpv[0] = x.x; rpv[1] = x.y; rpv[2] = y.x; rpv[3] = y.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double v = Rv[0] * Pr[j];
+                v = pm_fma(Rv[1], Pr[4 + j], v);
+                v = pm_fma(Rv[2], Pr[8 + j], v);
+                rpv[j] = pm_fma(Rv[3], Pr[12 + j], v);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = lpv[j] * rpv[j];
+        pm_lp_mul(col, pk_site_lik(pi, o));
+    }
+}
+
 // One workgroup per (local particle, left root r1): all pairs (r1, r2 > r1) x M sub-samples.  Thread c owns
 // canonical column c (sites c, c+256, ...) of every pair; column sums go to LDS and each wave then runs the
 // canonical tree for whole (pair, sub-sample) rows, so there is one barrier per workgroup instead of two per
@@ -905,40 +960,51 @@ __device__ __forceinline__ double pk_uniform(double v) {
     hi = __builtin_amdgcn_readfirstlane(hi);
     return __hiloint2double(hi, lo);
 }
-#define PK_TWIST_LDS_ROWS 8             // (pair, sub-sample) rows reduced per pass
+#define PK_TWIST_LDS_ROWS 8              // (pair, sub-sample) rows staged and reduced per pass
 __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist_args ta) {
     __shared__ double cols[PK_TWIST_LDS_ROWS][PK_COLS];
+    __shared__ __attribute__((aligned(16))) double Psh[PK_TWIST_LDS_ROWS][32];
+    __shared__ __attribute__((aligned(16))) double tab[PK_TWIST_LDS_ROWS][2][5][4];
     const pk_rank_args& a = ta.a;
     const int n = a.n, M = ta.M, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int k = blockIdx.x / (n - 1), r1 = blockIdx.x - k * (n - 1), kg = a.k0 + k;
     const int32_t* ro = ta.roots_ad + (size_t)kg * a.N;
     const int32_t* co = ta.cnt_ad + (size_t)kg * a.N;
     const double* rl = ta.rootll_ad + (size_t)kg * a.N;
-    const double* Lp = pk_node_ptr(a, ro[r1]);
+    const int idl = ro[r1];
+    const double* Lp = pk_node_ptr(a, idl);
+    const bool cL = a.leaf_codes && idl < a.N;           // workgroup-uniform
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     // pair index of (r1, r1+1): sum_{i<r1} (n-1-i)
     const int t0 = r1 * (n - 1) - r1 * (r1 - 1) / 2;
     const int nrows = (n - 1 - r1) * M;                  // rows of this workgroup: (r2 - r1 - 1) * M + m
+    const double* Pblock = ta.tw_P + ((size_t)k * ta.J + (size_t)t0 * M) * 32;   // rows are contiguous in j
     for (int base = 0; base < nrows; base += PK_TWIST_LDS_ROWS) {
         const int cnt = nrows - base < PK_TWIST_LDS_ROWS ? nrows - base : PK_TWIST_LDS_ROWS;
+        // stage the transition matrices of this pass and the leaf lookup tables built from them: one global
+        // round trip per pass instead of one per row
+        for (int i = tid; i < cnt * 32; i += PK_COLS) Psh[i >> 5][i & 31] = Pblock[(size_t)(base + (i >> 5)) * 32 + (i & 31)];
+        __syncthreads();
+        for (int i = tid; i < cnt * 40; i += PK_COLS) {
+            const int q = i / 40, e = i - q * 40, side = e / 20;
+            pk_build_leaf_table(&Psh[q][side * 16], tab[q][side], e - side * 20);
+        }
+        __syncthreads();
         for (int q = 0; q < cnt; ++q) {
-            const int row = base + q, r2 = r1 + 1 + row / M, m = row - (row / M) * M;
-            const double* Rp = pk_node_ptr(a, ro[r2]);
-            const double* P = ta.tw_P + ((size_t)k * ta.J + (size_t)(t0 + r2 - r1 - 1) * M + m) * 32;
+            const int row = base + q, r2 = r1 + 1 + row / M;
+            const int idr = ro[r2];
+            const double* Rp = pk_node_ptr(a, idr);
+            const bool cR = a.leaf_codes && idr < a.N;
             double Pl[16], Pr[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { Pl[u] = pk_uniform(P[u]); Pr[u] = P[16 + u]; }   // P_l in SGPRs, P_r in VGPRs
+            for (int u = 0; u < 16; ++u) { Pl[u] = pk_uniform(Psh[q][u]); Pr[u] = Psh[q][16 + u]; }   // P_l in SGPRs
             pm_lp col = pm_lp_init();
-            double Ln[4], Rn[4];                                 // software pipeline: next step's rows
-            if (tid < a.S) { pk_load4(Lp + (size_t)tid * 4, Ln); pk_load4(Rp + (size_t)tid * 4, Rn); }
-            for (int s = tid; s < a.S; s += PK_COLS) {
-                double Lv[4], Rv[4], o[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { Lv[u] = Ln[u]; Rv[u] = Rn[u]; }
-                if (s + PK_COLS < a.S) { pk_load4(Lp + (size_t)(s + PK_COLS) * 4, Ln); pk_load4(Rp + (size_t)(s + PK_COLS) * 4, Rn); }
-                pk_merge_site(Lv, Rv, Pl, Pr, o);
-                pm_lp_mul(col, pk_site_lik(pi, o));
-            }
+            const uint8_t* Lc = a.leaf_codes + (cL ? (size_t)idl * a.S : 0);
+            const uint8_t* Rc = a.leaf_codes + (cR ? (size_t)idr * a.S : 0);
+            if (cL && cR) pk_twist_row<true, true>(a, Lp, Rp, Lc, Rc, Pl, Pr, tab[q][0], tab[q][1], pi, col);
+            else if (cL) pk_twist_row<true, false>(a, Lp, Rp, Lc, Rc, Pl, Pr, tab[q][0], tab[q][1], pi, col);
+            else if (cR) pk_twist_row<false, true>(a, Lp, Rp, Lc, Rc, Pl, Pr, tab[q][0], tab[q][1], pi, col);
+            else pk_twist_row<false, false>(a, Lp, Rp, Lc, Rc, Pl, Pr, tab[q][0], tab[q][1], pi, col);
             cols[q][tid] = pm_lp_finish(col);
         }
         __syncthreads();
