@@ -300,3 +300,52 @@ def test_twisted_sweep_bit_exact_vs_oracle(dataset, K, M, jc):
         ref2 = O.sweep_twisted(g, Q, PI, lam, lam, K, M, 3)
         np.testing.assert_array_equal(out['ancestors'], ref2['ancestors'])
         assert out['logZ'] == pytest.approx(ref2['logZ'], rel=1e-9)
+
+
+def test_many_taxa_bookkeeping_paths():
+    """N = 70 > 64: the wave-per-particle bookkeeping loops over slots in strides of 64; leaf rows that are
+    neither one-hot nor all-ones disable the leaf-code fast path (generic rows)."""
+    d = synthetic_alignment(70, 40)
+    g = d['genome'].copy()
+    K = 12
+    lam = np.full(69, 10.0)
+    for generic in (False, True):
+        if generic:
+            g[3, 5] = [0.5, 0.5, 0.0, 0.0]                   # an ambiguity row: not codable
+        ctx = make_ctx(g, K, O.jc_Q(), jc=True)
+        out = ctx.sweep(11)
+        ref = CO.sweep(g, O.jc_Q(), PI, lam, lam, K, 11, jc=True)
+        np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
+        np.testing.assert_array_equal(out['merges'], ref['merges'])
+        assert_bit_equal(out['log_weights'], ref['log_weights'], "log_weights N=70 generic=%s" % generic)
+        assert_bit_equal(out['logZ'], ref['logZ'], "logZ")
+        ctx.close()
+
+
+def test_leaf_code_path_equals_generic_path(primate, monkeypatch):
+    """The 1-byte leaf codes are an access-path optimisation only: same bits as reading the rows."""
+    Q = O.get_Q(O.init_y_q())
+    a = make_ctx(primate, 96, Q)
+    ra = a.sweep(5)
+    a.close()
+    monkeypatch.setenv("PHYLO_NO_LEAF_CODES", "1")
+    b = make_ctx(primate, 96, Q)
+    rb = b.sweep(5)
+    b.close()
+    assert_bit_equal(ra['log_weights'], rb['log_weights'], "coded vs generic leaves")
+    np.testing.assert_array_equal(ra['ancestors'], rb['ancestors'])
+
+
+def test_hohna_ds1_config4_shape():
+    """BASELINE config 3 shape on one GPU: DS1 (27 taxa, 1949 sites, gaps), K = 256 against the oracle."""
+    g = load_dataset('hohna_data_1')['genome']
+    N = g.shape[0]
+    lam = np.full(N - 1, 10.0)
+    Q = O.get_Q(O.init_y_q())
+    ctx = make_ctx(g, 256, Q)
+    out = ctx.sweep(0)
+    ref = CO.sweep(g, Q, PI, lam, lam, 256, 0)
+    np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
+    assert_bit_equal(out['log_weights'], ref['log_weights'], "DS1 log_weights")
+    assert_bit_equal(out['logZ'], ref['logZ'], "DS1 logZ")
+    ctx.close()

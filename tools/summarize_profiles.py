@@ -20,8 +20,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    f = glob.glob(os.path.join(src, pattern))
-    return f[0] if f else None
+    f = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+    return f[-1] if f else None          # gpurun merges runs into the same directory: take the newest
 
 
 lines = ["# rocprofv3 summary, round %s" % tag, "",
