@@ -35,7 +35,7 @@ struct phylo_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> kev;         // per-merge-launch events (PHYLO_TIME_KERNELS)
     std::string err;
-    bool have_leaves = false, have_model = false, swept = false;
+    bool have_leaves = false, have_model = false, swept = false, state_ready = false;
     int jc = 0;
     std::vector<double> h_lam_l, h_lam_r, h_ldf;
     // model + leaves
@@ -56,7 +56,8 @@ struct phylo_ctx {
     int32_t* d_merges = nullptr;         // [(N-1)][Kloc][2]
     int64_t* d_anc = nullptr;            // [(N-2)][Kloc]
     uint64_t* d_cdf[2] = {nullptr, nullptr};   // [K], double-buffered across rank events
-    unsigned int* d_counter = nullptr;   // (unused)
+    unsigned int* d_counter = nullptr;   // [0] scan->bookkeeping flag, [1] hand-off timeout word
+    unsigned int epoch = 0;              // monotone hand-off epoch (never reset, never 0)
     const double** d_pool_ptrs = nullptr; // [world] pool base of every rank (peer mappings)
     // twisted proposal (allocated on first use)
     int32_t *d_roots_ad = nullptr, *d_cnt_ad = nullptr;
@@ -162,6 +163,7 @@ void free_sweep_state(phylo_ctx* c) {
 
 int alloc_sweep_state(phylo_ctx* c) {
     free_sweep_state(c);
+    c->state_ready = false;
     const size_t R = (size_t)c->N - 1, K = c->K, Kl = c->Kloc, N = c->N, S = c->S;
     CHK(dalloc(c, &c->d_pool, R * Kl * S * 4));
     CHK(dalloc(c, &c->d_nodell, N + R * K));
@@ -183,17 +185,26 @@ int alloc_sweep_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_cdf[0], K));
     CHK(dalloc(c, &c->d_cdf[1], K));
     CHK(dalloc(c, &c->d_counter, ((size_t)N + 3) & ~(size_t)3));
+    HIPCHK(c, hipMemset(c->d_counter, 0, (((size_t)N + 3) & ~(size_t)3) * sizeof(unsigned int)));
     CHK(dalloc(c, &c->d_pool_ptrs, (size_t)c->world));
     std::vector<void*> ptrs;
     int rc = phylo_comm_map_pools(c->comm, c->d_pool, &ptrs, c->stream, &c->err);
     if (rc != PHYLO_OK) return rc;
     HIPCHK(c, hipMemcpy((void*)c->d_pool_ptrs, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice));
+    c->state_ready = true;
     return PHYLO_OK;
+}
+
+// The sweep state (node pool = (N-1) K_local S 32 bytes) is allocated on first use, so that a context created
+// with the GLOBAL particle count and then sharded by phylo_comm_init never asks for the unsharded pool.
+int ensure_sweep_state(phylo_ctx* c) {
+    if (c->state_ready) return PHYLO_OK;
+    return alloc_sweep_state(c);
 }
 
 // leaf node log-likelihoods sum_s log(pi . leaf[s]) (depend on pi and the leaves)
 int refresh_leaf_ll(phylo_ctx* c) {
-    if (!(c->have_leaves && c->have_model)) return PHYLO_OK;
+    if (!(c->have_leaves && c->have_model && c->state_ready)) return PHYLO_OK;
     hipLaunchKernelGGL(pk_row_loglik, dim3(c->N), dim3(PK_COLS), 0, c->stream, c->d_leaves, c->d_pi, c->S,
                        c->d_nodell);
     return launch_check(c, "pk_row_loglik(leaves)");
@@ -247,7 +258,6 @@ int phylo_create(const int* device_ids, int n_gpus, int K, int N, int S, int A, 
         if ((rc = dalloc(c, &c->d_ldf, (size_t)N + 1)) != PHYLO_OK) break;
         if ((rc = dalloc(c, &c->d_leaves, (size_t)N * S * 4)) != PHYLO_OK) break;
         if ((rc = dalloc(c, &c->d_leaf_codes, (size_t)N * S)) != PHYLO_OK) break;
-        if ((rc = alloc_sweep_state(c)) != PHYLO_OK) break;
         // table of log (2 max(c,2) - 3)!! by leaf count c = 0..N
         c->h_ldf.resize((size_t)N + 1);
         for (int cnt = 0; cnt <= N; ++cnt) c->h_ldf[cnt] = host_log_double_factorial(2 * (cnt > 2 ? cnt : 2) - 3);
@@ -513,6 +523,10 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     (void)M;
     if (!c->have_leaves || !c->have_model)
         return fail(c, PHYLO_ESTATE, "phylo_set_leaves and phylo_set_model must be called before a sweep");
+    if (!c->state_ready) {
+        CHK(ensure_sweep_state(c));
+        CHK(refresh_leaf_ll(c));
+    }
     const int N = c->N, K = c->K, Kl = c->Kloc, S = c->S, R = N - 1;
     const bool twist = (flags & PHYLO_TWISTING) != 0;
     if (twist) {
@@ -544,6 +558,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         }
     }
     int launches = 0;
+    const bool fuse_scan = !twist && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
     const size_t lds = pk_book_lds_bytes(N);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (!twist) {
@@ -604,6 +619,17 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
             hipLaunchKernelGGL(pk_twist_tables, dim3(cdiv(K, 128)), dim3(128), 0, c->stream, ta);
             CHK(launch_check(c, "pk_twist_tables"));
             launches += 5;
+        } else if (r > 0 && fuse_scan) {
+            // scan of log w_{r-1} and the bookkeeping of rank event r in one launch
+            b.scan_logw = c->d_logw + (size_t)(r - 1) * K;
+            b.scan_cdf = c->d_cdf[cur];
+            b.scan_lse = c->d_lse + (r - 1);
+            b.flag = c->d_counter; b.epoch = ++c->epoch; b.timeout_word = c->d_counter + 1;
+            if (c->epoch == 0xffffffffu) c->epoch = 0;
+            const size_t lds2 = lds > pk_scan_lds_bytes(K) ? lds : pk_scan_lds_bytes(K);
+            hipLaunchKernelGGL(pk_rank_scan_book, dim3(K + 1), dim3(PK_COLS), lds2, c->stream, b);
+            CHK(launch_check(c, "pk_rank_scan_book"));
+            ++launches;
         } else {
             hipLaunchKernelGGL(pk_rank_book, dim3(K), dim3(64), lds, c->stream, b);
             CHK(launch_check(c, "pk_rank_book"));
@@ -623,11 +649,13 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
                 CHK(launch_check(c, "pk_fix_rootll"));
                 ++launches;
             }
-            hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream,
-                               (const double*)(c->d_logw + (size_t)r * K), K, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
-                               c->d_lse + r);
-            CHK(launch_check(c, "pk_resample_scan"));
-            ++launches;
+            if (!fuse_scan || twist || r + 1 == R) {           // otherwise the next rank event's launch scans these weights
+                hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream,
+                                   (const double*)(c->d_logw + (size_t)r * K), K, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
+                                   c->d_lse + r);
+                CHK(launch_check(c, "pk_resample_scan"));
+                ++launches;
+            }
         }
     }
     hipLaunchKernelGGL(pk_logz_total, dim3(1), dim3(64), 0, c->stream, (const double*)c->d_lse, R, c->d_lse + R);
@@ -660,6 +688,14 @@ int phylo_sweep_fetch(phylo_ctx* c, double* log_weights, double* log_lik, double
     if (!c->swept) return fail(c, PHYLO_ESTATE, "no sweep has been run");
     const size_t R = (size_t)c->N - 1, K = c->K, Kl = c->Kloc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        unsigned int tmo = 0;
+        HIPCHK(c, hipMemcpy(&tmo, c->d_counter + 1, sizeof tmo, hipMemcpyDeviceToHost));
+        if (tmo) {
+            HIPCHK(c, hipMemset(c->d_counter + 1, 0, sizeof tmo));
+            return fail(c, PHYLO_EHIP, "scan -> bookkeeping hand-off timed out inside a launch; results are invalid");
+        }
+    }
     // log_weights / log_lik are stored with global columns; hand back this rank's columns
     if (log_weights)
         HIPCHK(c, hipMemcpy2D(log_weights, Kl * 8, c->d_logw + c->k0, K * 8, Kl * 8, R, hipMemcpyDeviceToHost));
@@ -739,7 +775,8 @@ int phylo_comm_init(phylo_ctx* c, int rank, int world, const char id[PHYLO_COMM_
     c->Kloc = c->K / world;
     c->k0 = rank * c->Kloc;
     c->swept = false;
-    CHK(alloc_sweep_state(c));
+    c->state_ready = false;
+    CHK(alloc_sweep_state(c));                             // collective: every rank maps every peer's pool here
     CHK(refresh_leaf_ll(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PHYLO_OK;

@@ -257,9 +257,11 @@ __device__ __forceinline__ void pk_scan_tile(const double* logw, int K, int base
 }
 
 // `stage`: K-element scratch for the integer weights between the two passes: LDS when it fits, else cdf[].
+// `publish`: the final cdf is written with agent-scope (write-through) 8-byte stores, because workgroups
+// of the SAME launch read it after a flag hand-off (pk_rank_scan_book).
 __device__ __forceinline__ void pk_scan_block(const double* logw, int K, uint64_t* __restrict__ cdf,
                                               double* __restrict__ lse_out, pk_scan_lds* sh,
-                                              unsigned long long* stage) {
+                                              unsigned long long* stage, bool publish = false) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool one_tile = K <= 8 * PK_COLS;
     double v[8];
@@ -337,7 +339,13 @@ __device__ __forceinline__ void pk_scan_block(const double* logw, int K, uint64_
         __syncthreads();
         unsigned long long run = carry + incl - local;
         for (int i = 0; i < wv; ++i) run += sh->u4[i];
-        if (lo + 8 <= K) {
+        if (publish) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (lo + j < K)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(cdf) + lo + j, run + e[j], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lo + 8 <= K) {
             ulonglong2* q = reinterpret_cast<ulonglong2*>(cdf + lo);
             q[0] = make_ulonglong2(run + e[0], run + e[1]);
             q[1] = make_ulonglong2(run + e[2], run + e[3]);
@@ -376,13 +384,17 @@ __device__ __forceinline__ int pk_cdf_search(const uint64_t* __restrict__ cdf, i
 
 // the same search by one wave: 64 probes per step.  The first round's probe addresses do not depend on the
 // threshold, so `total` and the coarse probes travel together: 2 dependent round trips for K <= 4096.
-__device__ __forceinline__ int pk_cdf_search_wave(const uint64_t* __restrict__ cdf, int K, uint64_t R, int lane) {
+__device__ __forceinline__ uint64_t pk_cdf_ld(const uint64_t* cdf, int i, bool agent) {
+    if (agent) return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(cdf) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return cdf[i];
+}
+__device__ __forceinline__ int pk_cdf_search_wave(const uint64_t* cdf, int K, uint64_t R, int lane, bool agent = false) {
     int lo = 0, hi = K;             // invariant: answer in [lo, hi), cdf[hi-1] > thr
     int step = (K + 63) >> 6;
     int p = (lane + 1) * step - 1;
     if (p > K - 1) p = K - 1;
-    const uint64_t total = cdf[K - 1];
-    uint64_t c = cdf[p];
+    const uint64_t total = pk_cdf_ld(cdf, K - 1, agent);
+    uint64_t c = pk_cdf_ld(cdf, p, agent);
     const uint64_t thr = pm_mulhi64(R, total);
     for (;;) {
         const unsigned long long mask = __ballot(c > thr);
@@ -396,7 +408,7 @@ __device__ __forceinline__ int pk_cdf_search_wave(const uint64_t* __restrict__ c
         step = (hi - lo + 63) >> 6;
         p = lo + (lane + 1) * step - 1;
         if (p > hi - 1) p = hi - 1;
-        c = cdf[p];
+        c = pk_cdf_ld(cdf, p, agent);
     }
     return lo;
 }
@@ -455,6 +467,10 @@ struct pk_rank_args {
     double* logw_r; double* ll_r;                         // [K] rows (global columns)
     int32_t* merges;                                      // [R][Kloc][2]
     int64_t* ancestors;                                   // [R-1][Kloc]
+    // scan -> bookkeeping hand-off inside ONE launch (pk_rank_scan_book): workgroup 0 scans log w_{r-1}, publishes
+    // cdf[] write-through and then stores `epoch` into *flag; the bookkeeping workgroups poll it (bounded).
+    const double* scan_logw; uint64_t* scan_cdf; double* scan_lse;
+    unsigned int* flag; unsigned int epoch; unsigned int* timeout_word;
     int32_t* child;                                       // [Kloc][2]: node ids merged at this rank event
     double* aux;                                          // [Kloc][PK_AUX]: weight terms for the merge epilogue
 };
@@ -504,11 +520,26 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
         const double hb_l0 = (local && lane <= a.r) ? a.bl[(size_t)lane * a.Kloc + k] : 0.0;
         const double hb_r0 = (local && lane <= a.r) ? a.br[(size_t)lane * a.Kloc + k] : 0.0;
         const double ldf0 = (lane <= a.ldf_n) ? a.ldf[lane] : 0.0;
+#pragma unroll 1
+        for (int b = lane; b < (n + 3) / 4; b += 64) {
+            const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_PAIR, (uint32_t)b, a.seed);
+            L.key[b * 4 + 0] = x.x; L.key[b * 4 + 1] = x.y; L.key[b * 4 + 2] = x.z; L.key[b * 4 + 3] = x.w;
+        }
         int anc = kg;
         if (a.r > 0) {
             const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_RESAMPLE, 0u, a.seed);
             const uint64_t R = ((uint64_t)x.y << 32) | x.x;
-            anc = pk_cdf_search_wave(a.cdf, a.K, R, lane);
+            if (a.flag) {                             // the scan runs in workgroup 0 of this launch: wait for its flag
+                unsigned int spins = 0;
+                while (__hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1u << 22)) {       // ~ seconds: give up loudly instead of hanging the GPU
+                        if (lane == 0) __hip_atomic_store(a.timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            anc = pk_cdf_search_wave(a.cdf, a.K, R, lane, a.flag != nullptr);
         }
         const int32_t* ro = a.roots_old + (size_t)anc * N;
         const int32_t* co = a.cnt_old + (size_t)anc * N;
@@ -519,12 +550,7 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
             L.misc[3] = anc;
             if (local) L.aux[AUX_LL_TILDE] = (a.r > 0) ? a.ll_prev[anc] : a.ll_tilde0;
         }
-        #pragma unroll 1
-        for (int b = lane; b < (n + 3) / 4; b += 64) {
-            const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_PAIR, (uint32_t)b, a.seed);
-            L.key[b * 4 + 0] = x.x; L.key[b * 4 + 1] = x.y; L.key[b * 4 + 2] = x.z; L.key[b * 4 + 3] = x.w;
-        }
-        if (lane <= a.r) { L.hbl[lane] = hb_l0; L.hbr[lane] = hb_r0; }
+                if (lane <= a.r) { L.hbl[lane] = hb_l0; L.hbr[lane] = hb_r0; }
         if (lane <= a.ldf_n) L.ldf[lane] = ldf0;
         #pragma unroll 1
         for (int j = lane + 64; j <= a.r; j += 64) {
@@ -636,6 +662,37 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
 __global__ __launch_bounds__(64) void pk_rank_book(const pk_rank_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int kg = blockIdx.x;
+    const pk_book_lds L = pk_book_carve(smem, a.N);
+    const bool local = kg >= a.k0 && kg < a.k0 + a.Kloc;
+    pk_book_particle(a, kg, local, L);
+    if (local && threadIdx.x < PK_AUX + 2) {
+        const int k = kg - a.k0;
+        if (threadIdx.x < PK_AUX) a.aux[(size_t)k * PK_AUX + threadIdx.x] = L.aux[threadIdx.x];
+        else a.child[k * 2 + (threadIdx.x - PK_AUX)] = L.misc[threadIdx.x - PK_AUX];
+    }
+}
+
+// Scan + bookkeeping in ONE launch: workgroup 0 (256 threads) runs the resampling scan of log w_{r-1} and
+// publishes the cdf; workgroups 1..K (their first wave) do the bookkeeping of particle blockIdx-1, overlapping
+// everything that does not depend on the resampling outcome with the scan and polling the flag just before
+// the index search.  Hand-off form: 8-byte agent-scope stores of the payload, every storing wave drained
+// (s_waitcnt vmcnt(0)), workgroup barrier, ONE agent-scope flag store; consumers poll the flag relaxed and read
+// the payload with agent-scope loads (cdna_hip_programming.md Guideline 16, "8-B agent atomics both sides").
+// Workgroup 0 is dispatched first and waits for nobody, so the launch cannot deadlock; the poll is bounded anyway.
+__global__ __launch_bounds__(PK_COLS) void pk_rank_scan_book(const pk_rank_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (blockIdx.x == 0) {
+        pk_scan_lds* sh = reinterpret_cast<pk_scan_lds*>(smem);
+        unsigned long long* stage = (a.K <= PK_SCAN_LDS_MAX_K) ? reinterpret_cast<unsigned long long*>(smem + sizeof(pk_scan_lds))
+                                                               : reinterpret_cast<unsigned long long*>(a.scan_cdf);
+        pk_scan_block(a.scan_logw, a.K, a.scan_cdf, a.scan_lse, sh, stage, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains its stores
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.flag, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (threadIdx.x >= 64) return;                              // bookkeeping uses one wave
+    const int kg = blockIdx.x - 1;
     const pk_book_lds L = pk_book_carve(smem, a.N);
     const bool local = kg >= a.k0 && kg < a.k0 + a.Kloc;
     pk_book_particle(a, kg, local, L);

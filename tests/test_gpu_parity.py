@@ -349,3 +349,39 @@ def test_hohna_ds1_config4_shape():
     assert_bit_equal(out['log_weights'], ref['log_weights'], "DS1 log_weights")
     assert_bit_equal(out['logZ'], ref['logZ'], "DS1 logZ")
     ctx.close()
+
+
+@pytest.mark.parametrize("N,S,K", [(2, 1, 1), (2, 5, 7), (3, 1, 4), (5, 300, 3000), (4, 17, 9000)])
+def test_sweep_edge_shapes(N, S, K):
+    """Smallest trees (one rank event, no resampling), single site, single particle, K beyond one scan tile
+    (2048) and beyond the LDS-staged scan (8192)."""
+    g = synthetic_alignment(N, S, seed=N * 1000 + S)['genome']
+    lam = np.full(N - 1, 10.0)
+    Q = O.get_Q(O.init_y_q())
+    ctx = make_ctx(g, K, Q)
+    out = ctx.sweep(2)
+    ref = CO.sweep(g, Q, PI, lam, lam, K, 2)
+    np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
+    np.testing.assert_array_equal(out['merges'], ref['merges'])
+    assert_bit_equal(out['log_weights'], ref['log_weights'], "log_weights")
+    assert_bit_equal(out['logZ'], ref['logZ'], "logZ")
+    if N >= 3:
+        tw = ctx.sweep(2, flags=_ffi.FLAGS_DEFAULT | _ffi.TWISTING, M=2)
+        rt = CO.sweep_twisted(g, Q, PI, lam, lam, K, 2, 2)
+        np.testing.assert_array_equal(tw['ancestors'], rt['ancestors'])
+        assert_bit_equal(tw['log_weights'], rt['log_weights'], "twisted log_weights")
+    ctx.close()
+
+
+def test_fused_scan_bookkeeping_launch(primate, monkeypatch):
+    """Opt-in single-launch scan + bookkeeping (bounded flag hand-off inside the launch): same bits."""
+    Q = O.get_Q(O.init_y_q())
+    a = make_ctx(primate, 200, Q)
+    ra = a.sweep(9)
+    monkeypatch.setenv("PHYLO_FUSE_SCAN", "1")
+    for seed in (9, 10, 11):
+        rb = a.sweep(seed)
+        if seed == 9:
+            assert_bit_equal(ra['log_weights'], rb['log_weights'], "fused vs separate launches")
+            np.testing.assert_array_equal(ra['ancestors'], rb['ancestors'])
+    a.close()
