@@ -237,9 +237,57 @@ class VCSMC:
             slices.append(sites_list)
         return slices
 
-    def train(self, epochs=100, batch_size=128, learning_rate=0.001, memory_optimization='on'):
+    def newick(self, k=0):
+        """Newick string of particle k's final tree, rebuilt from the integer merge records of the last
+        sweep (branch lengths = the sampled left/right branches of each coalescence)."""
+        K, N = self.K, self.N
+        tab = [[str(t) for t in self.taxa] for _ in range(K)]
+        for r in range(N - 1):
+            if r > 0:
+                idx = self.ancestors[r - 1]
+                tab = [list(tab[i]) for i in idx]
+            if self._twisted:
+                rems = [[i for i in range(N - r - 1, -1, -1) if i != a and i != b] for a, b in self.merges[r]]
+            else:
+                rems = rng.pair_order(K, N - r, self._last_seed, r)[1]
+            new = []
+            for kk in range(K):
+                a, b = self.merges[r][kk]
+                node = '(%s:%.6g,%s:%.6g)' % (tab[kk][a], self.left_branches[r, kk], tab[kk][b], self.right_branches[r, kk])
+                new.append([tab[kk][i] for i in rems[kk]] + [node])
+            tab = new
+        return tab[k][0] + ';'
+
+    def _save_results(self, save_dir, initial, history):
+        """run_parameters.txt and results.p with the reference's keys (vcsmc.py:503-516, 618-642); no plots."""
+        import os
+        import pickle
+        os.makedirs(save_dir, exist_ok=True)
+        with open(os.path.join(save_dir, "run_parameters.txt"), "w") as rp:
+            rp.write('Initial evaluation of ELBO : ' + str(initial) + '\n')
+            for key, v in vars(self.args).items():
+                rp.write(str(key) + ' : ' + str(v) + '\n')
+            rp.write('optimizer step: not part of this build (parameters stay at their initial values)')
+        elbos = np.asarray(history['cost'])
+        best = int(np.argmax(elbos)) if len(elbos) else 0
+        resultDict = {'cost': elbos, 'nParticles': self.K, 'nTaxa': self.N, 'lr': self.lr,
+                      'log_weights': np.asarray(history['log_weights']), 'Qmatrices': np.asarray(history['Qmatrices']),
+                      'left_branches': history['left_branches'], 'right_branches': history['right_branches'],
+                      'log_lik': np.asarray(history['log_lik']), 'll_tilde': np.asarray(history['ll_tilde']),
+                      'log_lik_R': np.asarray(history['log_lik_R']),
+                      'jump_chain_evolution': history['jump_chain_evolution'], 'best_epoch': best,
+                      'best_log_lik': history['log_lik_R'][best] if len(elbos) else None,
+                      'best_jump_chain': history['jump_chain_evolution'][best] if len(elbos) else None,
+                      'best_newick': history['newick'][best] if len(elbos) else None}
+        with open(os.path.join(save_dir, 'results.p'), 'wb') as f:
+            pickle.dump(resultDict, f)
+        return resultDict
+
+    def train(self, epochs=100, batch_size=128, learning_rate=0.001, memory_optimization='on', save_dir='auto'):
         """vcsmc.py:466-645 without the optimiser step: one full-S evaluation sweep per epoch (the sweep the
-        reference reports, vcsmc.py:538-551), same printed lines.  Returns the per-epoch ELBOs."""
+        reference reports, vcsmc.py:538-551), same printed lines, and the reference's result artefacts
+        (results/<dataset>/<nested>/<K>/<timestamp>/{run_parameters.txt,results.p}; save_dir=None to skip).
+        Returns the per-epoch ELBOs."""
         self.lr = learning_rate
         print('================= Dataset shape: KxNxSxA =================')
         print((self.K, self.N, self.S, self.A))
@@ -251,9 +299,18 @@ class VCSMC:
         print('===================')
         print('Training begins --')
         elbos = []
+        hist = {k: [] for k in ('cost', 'log_weights', 'Qmatrices', 'left_branches', 'right_branches', 'log_lik', 'll_tilde',
+                                'log_lik_R', 'jump_chain_evolution', 'newick')}
         for i in range(epochs):
             bt = datetime.now()
             elbo = self.sample_phylogenies()
+            best_k = int(np.argmax(self.log_likelihood_R))
+            for key, val in (('cost', elbo), ('log_weights', self.log_weights), ('Qmatrices', self.Qmatrix),
+                             ('left_branches', self.left_branches), ('right_branches', self.right_branches),
+                             ('log_lik', self.log_likelihood), ('ll_tilde', self.log_likelihood_tilde),
+                             ('log_lik_R', self.log_likelihood_R), ('jump_chain_evolution', self.jump_chains),
+                             ('newick', self.newick(best_k))):
+                hist[key].append(val)
             print('Epoch', i + 1)
             print('ELBO\n', round(elbo, 3))
             print('Stationary probabilities\n', self.stationary_probs)
@@ -265,4 +322,12 @@ class VCSMC:
             print('Time spent\n', at - bt, '\n-----------------------------------------')
         print("Done training.")
         self.elbos = np.asarray(elbos)
+        if save_dir is not None:
+            if save_dir == 'auto':                   # vcsmc.py:504-507
+                tm = str(datetime.now())
+                save_dir = './results/' + str(getattr(self.args, 'dataset', 'data')) + '/' + str(getattr(self.args, 'nested', False)) + \
+                    '/' + str(getattr(self.args, 'n_particles', self.K)) + '/' + (tm[:10] + '-' + tm[11:13] + tm[14:16] + tm[17:19]) + '/'
+            self.results = self._save_results(save_dir, initial, hist)
+            self.save_dir = save_dir
+            print("Finished...")
         return self.elbos

@@ -103,9 +103,27 @@ def test_csmc_sample_phylogenies_runs():
     c.close()
 
 
-def test_runner_end_to_end(capsys):
+def test_runner_end_to_end(capsys, tmp_path, monkeypatch):
+    import glob
+    import pickle
     import runner
+    monkeypatch.chdir(tmp_path)
     elbos = runner.main(['--dataset', 'primate_data_wang', '--n_particles', '16', '--jcmodel', 'true', '--num_epoch', '2'])
     assert len(elbos) == 2 and np.isfinite(elbos).all()
     text = capsys.readouterr().out
     assert 'Initial evaluation of ELBO' in text and 'Epoch 2' in text and 'Done training.' in text
+    # the reference's result artefacts (vcsmc.py:503-516, 622-642)
+    out = glob.glob(str(tmp_path / 'results' / 'primate_data_wang' / 'False' / '16' / '*'))
+    assert len(out) == 1
+    assert 'n_particles : 16' in open(out[0] + '/run_parameters.txt').read()
+    res = pickle.load(open(out[0] + '/results.p', 'rb'))
+    for key in ('cost', 'nParticles', 'nTaxa', 'lr', 'log_weights', 'Qmatrices', 'left_branches', 'right_branches',
+                'log_lik', 'll_tilde', 'log_lik_R', 'jump_chain_evolution', 'best_epoch', 'best_log_lik', 'best_jump_chain'):
+        assert key in res, key
+    assert res['log_weights'].shape == (2, 8, 16) and res['nTaxa'] == 9
+    nwk = res['best_newick']
+    assert nwk.endswith(';') and nwk.count('(') == 8 and all(('S%d:' % i) in nwk for i in range(9))
+    # twisted proposal through the CLI (--twisting is the README's spelling of --nested)
+    elbos = runner.main(['--dataset', 'primate_data_wang', '--n_particles', '8', '--twisting', 'true', '--M', '2',
+                         '--num_epoch', '1'])
+    assert np.isfinite(elbos).all()
