@@ -26,8 +26,9 @@ def one(pattern):
 
 lines = ["# rocprofv3 summary, round %s" % tag, "",
          "Command: `python bench.py --steps 30 --warmup 3 --no-cpu-baseline` (primate.p N=12 S=898, GTR-init, K=2048;",
-         "default = 3 sweeps in flight; `--streams 1` = one sweep at a time).  Raw tables: `%s_kernel_stats_*.csv`." % tag, ""]
-for name in ("default", "1stream"):
+         "default = 3 sweeps in flight; `--streams 1` = one sweep at a time; `twist` = `--twisting --M 1 --streams 1`;",
+         "`ds1` = `--dataset hohna_data_1 --n_particles 4096 --streams 1`).  Raw tables: `%s_kernel_stats_*.csv`." % tag, ""]
+for name in ("default", "1stream", "twist", "ds1"):
     st = one("trace_%s/*/*_kernel_stats.csv" % name)
     if not st:
         continue
