@@ -33,8 +33,8 @@ HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measu
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=20)
-    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--steps', type=int, default=60)
+    p.add_argument('--warmup', type=int, default=6)
     p.add_argument('--dataset', default='primate_data')
     p.add_argument('--n_particles', type=int, default=2048, help='particles PER GPU')
     p.add_argument('--jcmodel', default=False, type=lambda x: str(x).lower() == 'true')
@@ -112,6 +112,9 @@ def main():
     n_streams = a.streams if a.streams > 0 else (3 if world == 1 else 1)
     if world > 1:
         n_streams = 1                                 # one RCCL communicator per context; keep it simple when sharded
+    pool_bytes = 32.0 * (N - 1) * a.n_particles * S   # node pool of one context
+    while n_streams > 1 and n_streams * pool_bytes > 200e9:
+        n_streams -= 1                                # every sweep in flight owns a pool; stay inside 288 GB of HBM
     ctxs = []
     for i in range(n_streams):
         c = _ffi.Context(K_global, N, S, device=local_rank % ndev)
