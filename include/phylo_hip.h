@@ -47,6 +47,9 @@ enum {
                                           Set = as the reference.  */
     PHYLO_TWISTING = 1u << 1,          /* twisted/nested proposal of vncsmc.py:295-416 (uses M)          */
     PHYLO_TIME_KERNELS = 1u << 2,      /* bracket every merge launch with HIP events (profiling runs)    */
+    PHYLO_EAGER_NODES = 1u << 3,       /* always store every new node's partial likelihoods.  Default: on one GPU, plain
+                                          proposal, S >= 8192, only nodes whose creator survives the next resampling
+                                          are written (the rest are dead stores); results are identical either way */
     PHYLO_FLAGS_DEFAULT = PHYLO_QUIRK_Q1_RAW_Q
 };
 

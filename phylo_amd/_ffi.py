@@ -17,6 +17,7 @@ PHYLO_OK = 0
 QUIRK_Q1_RAW_Q = 1 << 0
 TWISTING = 1 << 1
 TIME_KERNELS = 1 << 2
+EAGER_NODES = 1 << 3
 FLAGS_DEFAULT = QUIRK_Q1_RAW_Q
 COMM_ID_BYTES = 128
 

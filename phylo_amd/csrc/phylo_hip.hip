@@ -52,7 +52,11 @@ struct phylo_ctx {
     double* d_lse = nullptr;             // [N-1] + total
     int32_t *d_roots[2] = {nullptr, nullptr}, *d_cnt[2] = {nullptr, nullptr};   // [K][N]
     double* d_rootll[2] = {nullptr, nullptr};                                   // [K][N]
-    int32_t* d_child = nullptr;          // [Kloc][2]
+    int32_t* d_child = nullptr;          // [(N-1)][Kloc][2]: children of every node (kept for lazy materialisation)
+    unsigned int* d_mark = nullptr;      // [(N-1)][K]: node is in the pool
+    int32_t* d_mat_list = nullptr;       // [K] nodes queued for materialisation at the current rank event
+    unsigned int* d_mat_count = nullptr; // [(N-1)] one counter per rank event (zeroed with the marks)
+    bool last_lazy = false;
     int32_t* d_merges = nullptr;         // [(N-1)][Kloc][2]
     int64_t* d_anc = nullptr;            // [(N-2)][Kloc]
     uint64_t* d_cdf[2] = {nullptr, nullptr};   // [K], double-buffered across rank events
@@ -149,7 +153,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->tw_capacity = 0;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
                     c->d_roots[0], c->d_roots[1], c->d_cnt[0], c->d_cnt[1], c->d_child, c->d_merges, c->d_anc,
-                    c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1], (void*)c->d_pool_ptrs};
+                    c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1], (void*)c->d_pool_ptrs, c->d_mark, c->d_mat_list};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_pool = c->d_nodell = c->d_bl = c->d_br = c->d_Pmat = c->d_logw = c->d_ll = c->d_aux = c->d_lse = nullptr;
@@ -159,6 +163,9 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_counter = nullptr;
     c->d_rootll[0] = c->d_rootll[1] = nullptr;
     c->d_pool_ptrs = nullptr;
+    c->d_mark = nullptr;
+    c->d_mat_list = nullptr;
+    c->d_mat_count = nullptr;
 }
 
 int alloc_sweep_state(phylo_ctx* c) {
@@ -179,7 +186,10 @@ int alloc_sweep_state(phylo_ctx* c) {
         CHK(dalloc(c, &c->d_cnt[i], K * N));
         CHK(dalloc(c, &c->d_rootll[i], K * N));
     }
-    CHK(dalloc(c, &c->d_child, Kl * 2));
+    CHK(dalloc(c, &c->d_child, R * Kl * 2));
+    CHK(dalloc(c, &c->d_mark, ((R * K + R + 3) & ~(size_t)3)));      // marks, then the per-rank queue counters
+    c->d_mat_count = c->d_mark + R * K;
+    CHK(dalloc(c, &c->d_mat_list, K));
     CHK(dalloc(c, &c->d_merges, R * Kl * 2));
     CHK(dalloc(c, &c->d_anc, (R > 0 ? R - 1 : 0) * Kl));
     CHK(dalloc(c, &c->d_cdf[0], K));
@@ -557,10 +567,16 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
             c->kev.push_back(e);
         }
     }
+    // lazy nodes: dead stores are most of the HBM traffic of the plain sweep (a node is read again only if its
+    // creator survives the next resampling).  Needs every reader on this GPU and the plain proposal.
+    // Pays when a node is large (HBM-bound merges); on small nodes the extra launch costs more than the stores.
+    const bool lazy_ok = !twist && c->comm.transport == 0 && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES");
+    const bool lazy = lazy_ok && (S >= 8192 || getenv("PHYLO_LAZY_NODES"));
     int launches = 0;
     const bool fuse_scan = !twist && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
     const size_t lds = pk_book_lds_bytes(N);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (lazy) HIPCHK(c, hipMemsetAsync(c->d_mark, 0, (((size_t)R * K + R + 3) & ~(size_t)3) * sizeof(unsigned int), c->stream));
     if (!twist) {
         hipLaunchKernelGGL(pk_sweep_draws, dim3(cdiv(2L * R * Kl, 64)), dim3(64), 0, c->stream, c->d_Q, c->d_lam_l, c->d_lam_r,
                            c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat);
@@ -594,7 +610,8 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         b.logw_r = c->d_logw + (size_t)r * K;
         b.ll_r = c->d_ll + (size_t)r * K;
         b.merges = c->d_merges; b.ancestors = c->d_anc;
-        b.child = c->d_child; b.aux = c->d_aux;
+        b.child = c->d_child + (size_t)r * Kl * 2; b.aux = c->d_aux;
+        b.lazy = lazy ? 1 : 0; b.mark = c->d_mark; b.child_all = c->d_child; b.Pmat_all = c->d_Pmat; b.mat_list = c->d_mat_list; b.mat_count = c->d_mat_count + r;
         if (twist) {
             pk_twist_args ta{};
             ta.a = b;
@@ -635,6 +652,11 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
             CHK(launch_check(c, "pk_rank_book"));
             ++launches;
         }
+        if (lazy && r > 0) {
+            hipLaunchKernelGGL(pk_materialize_adopted, dim3(cdiv(S, PK_MAT_TILE), K), dim3(PK_COLS), 0, c->stream, b);
+            CHK(launch_check(c, "pk_materialize_adopted"));
+            ++launches;
+        }
         if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r], c->stream));
         hipLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
         CHK(launch_check(c, "pk_rank_merge"));
@@ -663,6 +685,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     ++launches;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->swept = true;
+    c->last_lazy = lazy;
     c->last_flags = flags;
     c->n_merge_events = timek ? R : 0;
     c->stats.n_launches = launches;
@@ -730,6 +753,17 @@ int phylo_sweep_node(phylo_ctx* c, int r, int k, double* out) {
     CHK(bind(c));
     if (!c->swept) return fail(c, PHYLO_ESTATE, "no sweep has been run");
     if (r < 0 || r >= c->N - 1 || k < 0 || k >= c->Kloc || !out) return fail(c, PHYLO_EINVAL, "bad (r, k)");
+    if (c->last_lazy) {                 // write every node that the lazy sweep skipped, oldest rank event first
+        pk_rank_args b{};
+        b.N = c->N; b.S = c->S; b.K = c->K; b.Kloc = c->Kloc; b.k0 = c->k0;
+        b.leaves = c->d_leaves; b.pool = c->d_pool; b.pool_ptrs = c->d_pool_ptrs;
+        b.mark = c->d_mark; b.child_all = c->d_child; b.Pmat_all = c->d_Pmat;
+        for (int rho = 0; rho < c->N - 1; ++rho) {
+            hipLaunchKernelGGL(pk_materialize_rank, dim3(c->Kloc), dim3(PK_COLS), 0, c->stream, b, rho);
+            CHK(launch_check(c, "pk_materialize_rank"));
+        }
+        c->last_lazy = false;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t node_sz = (size_t)c->S * 4;
     HIPCHK(c, hipMemcpy(out, c->d_pool + ((size_t)r * c->Kloc + k) * node_sz, node_sz * 8, hipMemcpyDeviceToHost));

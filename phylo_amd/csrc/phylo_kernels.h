@@ -471,7 +471,14 @@ struct pk_rank_args {
     // cdf[] write-through and then stores `epoch` into *flag; the bookkeeping workgroups poll it (bounded).
     const double* scan_logw; uint64_t* scan_cdf; double* scan_lse;
     unsigned int* flag; unsigned int epoch; unsigned int* timeout_word;
-    int32_t* child;                                       // [Kloc][2]: node ids merged at this rank event
+    // lazy nodes (single GPU, plain proposal): the merge kernel does not store the new node; a node is written
+    // only when some particle adopts its creator's table at the next resampling (pk_materialize_node)
+    int lazy;
+    unsigned int* mark;                                   // [R][K] 0/1: node (r, k) is in the pool
+    int32_t* mat_list; unsigned int* mat_count;           // nodes of rank event r-1 adopted at this rank event
+    const int32_t* child_all;                             // [R][Kloc][2] children of every node created so far
+    const double* Pmat_all;                               // [R][Kloc][32]
+    int32_t* child;                                       // [Kloc][2] (row r of child_all): node ids merged at this rank event
     double* aux;                                          // [Kloc][PK_AUX]: weight terms for the merge epilogue
 };
 
@@ -656,6 +663,50 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
     __syncthreads();
 }
 
+// Write node (rho, kappa) into the pool: the same merge, row per thread, no likelihood.  Called by ONE wave.
+__device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int id);
+__device__ __forceinline__ void pk_materialize_node(const pk_rank_args& a, int rho, int kappa, int lane, int nthreads,
+                                                    int s_begin, int s_end) {
+    const int k = kappa - a.k0;
+    const int32_t* ch = a.child_all + ((size_t)rho * a.Kloc + k) * 2;
+    const double* Lp = pk_node_ptr(a, ch[0]);
+    const double* Rp = pk_node_ptr(a, ch[1]);
+    const double* P = a.Pmat_all + ((size_t)rho * a.Kloc + k) * 32;
+    double Pl[16], Pr[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { Pl[j] = P[j]; Pr[j] = P[16 + j]; }
+    double* out = a.pool + ((size_t)rho * a.Kloc + k) * (size_t)a.S * 4;
+    for (int s = s_begin + lane; s < s_end; s += nthreads) {
+        double Lv[4], Rv[4], o[4];
+        pk_load4(Lp + (size_t)s * 4, Lv);
+        pk_load4(Rp + (size_t)s * 4, Rv);
+        pk_merge_site(Lv, Rv, Pl, Pr, o);
+        pk_store4(out + (size_t)s * 4, o);
+    }
+}
+
+// After the bookkeeping of rank event r: the nodes of rank event r-1 whose creator was adopted by some particle
+// are now live and get written; their children are leaves or nodes that were adopted, hence written, at an
+// earlier rank event.  Grid (site tiles, K): rows beyond the number of queued nodes exit at once (few distinct
+// ancestors survive a resampling); a node is spread over ceil(S / 1024) workgroups so that a large node is
+// not limited to one CU's bandwidth.
+#define PK_MAT_TILE 1024
+__global__ __launch_bounds__(PK_COLS) void pk_materialize_adopted(const pk_rank_args a) {
+    if (blockIdx.y >= *a.mat_count) return;
+    const int node = a.mat_list[blockIdx.y];
+    const int s0 = blockIdx.x * PK_MAT_TILE, s1 = s0 + PK_MAT_TILE < a.S ? s0 + PK_MAT_TILE : a.S;
+    pk_materialize_node(a, a.r - 1, node, threadIdx.x, PK_COLS, s0, s1);
+}
+
+// every node of rank event rho (test surface: phylo_sweep_node after a lazy sweep)
+__global__ __launch_bounds__(PK_COLS) void pk_materialize_rank(const pk_rank_args a, int rho) {
+    const int k = blockIdx.x;
+    if (a.mark[(size_t)rho * a.K + a.k0 + k]) return;
+    pk_materialize_node(a, rho, a.k0 + k, threadIdx.x, PK_COLS, 0, a.S);
+    __syncthreads();
+    if (threadIdx.x == 0) a.mark[(size_t)rho * a.K + a.k0 + k] = 1u;
+}
+
 // Bookkeeping kernel: one 64-thread workgroup (one wave) per GLOBAL particle.  Particles of this rank's
 // shard also get their child node ids and weight terms written for the merge kernel; for the others only the
 // replicated integer state (root tables) is advanced.
@@ -669,6 +720,12 @@ __global__ __launch_bounds__(64) void pk_rank_book(const pk_rank_args a) {
         const int k = kg - a.k0;
         if (threadIdx.x < PK_AUX) a.aux[(size_t)k * PK_AUX + threadIdx.x] = L.aux[threadIdx.x];
         else a.child[k * 2 + (threadIdx.x - PK_AUX)] = L.misc[threadIdx.x - PK_AUX];
+    }
+    if (a.lazy && a.r > 0 && threadIdx.x == 0) {
+        // this particle adopted the table of `anc`: the node anc created at the previous rank event is now live.
+        // The first adopter queues it for pk_materialize_adopted.
+        const int anc = L.misc[3];
+        if (atomicExch(a.mark + (size_t)(a.r - 1) * a.K + anc, 1u) == 0u) a.mat_list[atomicAdd(a.mat_count, 1u)] = anc;
     }
 }
 
@@ -700,6 +757,12 @@ __global__ __launch_bounds__(PK_COLS) void pk_rank_scan_book(const pk_rank_args 
         const int k = kg - a.k0;
         if (threadIdx.x < PK_AUX) a.aux[(size_t)k * PK_AUX + threadIdx.x] = L.aux[threadIdx.x];
         else a.child[k * 2 + (threadIdx.x - PK_AUX)] = L.misc[threadIdx.x - PK_AUX];
+    }
+    if (a.lazy && a.r > 0 && threadIdx.x == 0) {
+        // this particle adopted the table of `anc`: the node anc created at the previous rank event is now live.
+        // The first adopter queues it for pk_materialize_adopted.
+        const int anc = L.misc[3];
+        if (atomicExch(a.mark + (size_t)(a.r - 1) * a.K + anc, 1u) == 0u) a.mat_list[atomicAdd(a.mat_count, 1u)] = anc;
     }
 }
 
@@ -752,7 +815,7 @@ __device__ __forceinline__ void pk_build_leaf_table(const double* __restrict__ P
     }
 }
 
-template <bool CL, bool CR>
+template <bool CL, bool CR, bool STORE>
 __device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, const double* Lp, const double* Rp,
                                               const uint8_t* Lc, const uint8_t* Rc, double* out,
                                               const double (&Plc)[4][2], const double (&Prc)[4][2],
@@ -817,7 +880,7 @@ __device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, const doubl
                 }
             }
             const double o[2] = {lp[0] * rp[0], lp[1] * rp[1]};
-            if (t ? vb : va) {
+            if (STORE && (t ? vb : va)) {
                 const pk_d2 ov = {o[0], o[1]};
                 __builtin_nontemporal_store(ov, reinterpret_cast<pk_d2*>(out + (size_t)(t ? sb : sa) * 4));
             }
@@ -855,13 +918,16 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a
         __syncthreads();
     }
     pm_lp col = pm_lp_init();
-    if (codedL) {
-        if (codedR) pk_merge_body<true, true>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);
-        else pk_merge_body<true, false>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);
-    } else {
-        if (codedR) pk_merge_body<false, true>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);
-        else pk_merge_body<false, false>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);
+#define PK_MERGE_DISPATCH(ST)                                                                              \
+    if (codedL) {                                                                                          \
+        if (codedR) pk_merge_body<true, true, ST>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);   \
+        else pk_merge_body<true, false, ST>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);         \
+    } else {                                                                                               \
+        if (codedR) pk_merge_body<false, true, ST>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);  \
+        else pk_merge_body<false, false, ST>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);        \
     }
+    if (a.lazy) { PK_MERGE_DISPATCH(false) } else { PK_MERGE_DISPATCH(true) }
+#undef PK_MERGE_DISPATCH
     cols[p + 128 * h] = pm_lp_finish(col);          // lane (p, h) owns canonical column p + 128 h
     __syncthreads();
     const double tot = pk_block_canon_sum(cols[tid], sh4);

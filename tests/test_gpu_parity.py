@@ -385,3 +385,33 @@ def test_fused_scan_bookkeeping_launch(primate, monkeypatch):
             assert_bit_equal(ra['log_weights'], rb['log_weights'], "fused vs separate launches")
             np.testing.assert_array_equal(ra['ancestors'], rb['ancestors'])
     a.close()
+
+
+def test_lazy_nodes_equal_eager_nodes(monkeypatch):
+    """Lazy nodes (only nodes whose creator survives the next resampling are written) are an access-path
+    optimisation: every output, and every node partial fetched afterwards, has the same bits."""
+    g = load_dataset('primate_data')['genome']
+    N = 12
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    K = 160
+    monkeypatch.setenv("PHYLO_LAZY_NODES", "1")
+    ctx = make_ctx(g, K, Q)
+    for seed in (0, 1):
+        out = ctx.sweep(seed)
+        ref = CO.sweep(g, Q, PI, lam, lam, K, seed, want_nodes=True)
+        np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
+        assert_bit_equal(out['log_weights'], ref['log_weights'], "lazy log_weights")
+        assert_bit_equal(out['logZ'], ref['logZ'], "lazy logZ")
+        for (r, k) in [(0, 0), (3, 17), (N - 2, K - 1), (5, 100)]:        # dead and live nodes alike
+            assert_bit_equal(ctx.sweep_node(r, k), ref['nodes'][r, k], "lazy node (%d,%d)" % (r, k))
+    ctx.close()
+    # large-S configuration where lazy nodes are the default
+    monkeypatch.delenv("PHYLO_LAZY_NODES")
+    d = synthetic_alignment(6, 9000)
+    ctx = make_ctx(d['genome'], 24, Q)
+    out = ctx.sweep(4)
+    ref = CO.sweep(d['genome'], Q, PI, np.full(5, 10.0), np.full(5, 10.0), 24, 4, want_nodes=True)
+    assert_bit_equal(out['log_weights'], ref['log_weights'], "lazy default, S=9000")
+    assert_bit_equal(ctx.sweep_node(2, 5), ref['nodes'][2, 5], "node")
+    ctx.close()
