@@ -3,6 +3,7 @@
 #include "../../include/phylo_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -657,10 +658,11 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
             CHK(launch_check(c, "pk_materialize_adopted"));
             ++launches;
         }
-        if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r], c->stream));
-        hipLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
+        if (timek)   // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
+            hipExtLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
+        else
+            hipLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
         CHK(launch_check(c, "pk_rank_merge"));
-        if (timek) HIPCHK(c, hipEventRecord(c->kev[2 * r + 1], c->stream));
         ++launches;
         {
             if (c->comm.transport != 0) {
