@@ -95,18 +95,16 @@ class CSMC:
         return '+'.join(sorted(s.split('+')))
 
     def extend_partial_state(self, jump_chain_KxN, j, i):
-        """csmc.py:237-257: two posets sampled uniformly (python's RNG, like the reference), fixed branch
-        lengths 2, 2."""
-        jump_chain_KxN[j, i + 1] = deepcopy(jump_chain_KxN[j, i])
-        sample = random.sample(jump_chain_KxN[j, i][0], 2)
-        q2 = 1 / self.ncr(len(jump_chain_KxN[j, i][0]), 2)
-        particle1, particle2 = sample[0], sample[1]
-        particle_coalesced = self.sort_string(particle1 + '+' + particle2)
-        jump_chain_KxN[j, i + 1][0].remove(particle1)
-        jump_chain_KxN[j, i + 1][0].remove(particle2)
-        jump_chain_KxN[j, i + 1][0].append(particle_coalesced)
-        bl1, bl2 = 2, 2
-        return particle1, particle2, particle_coalesced, bl1, bl2, q2, jump_chain_KxN
+        """csmc.py:237-257: particle j's next jump-chain entry: two posets drawn uniformly without replacement
+        (python's RNG, like the reference) are replaced by their sorted union; branch lengths are fixed at 2, 2;
+        q2 = 1 / C(#posets, 2)."""
+        current = jump_chain_KxN[j, i][0]
+        first, second = random.sample(current, 2)
+        merged = self.sort_string(first + '+' + second)
+        nxt = deepcopy(jump_chain_KxN[j, i])
+        nxt[0] = [p for p in nxt[0] if p != first and p != second] + [merged]
+        jump_chain_KxN[j, i + 1] = nxt
+        return first, second, merged, 2, 2, 1 / self.ncr(len(current), 2), jump_chain_KxN
 
     def conditional_likelihood(self, left, right, left_branch, right_branch):
         """csmc.py:300-309: (left.data @ expm(Q bl)) * (right.data @ expm(Q br)), [S,4]."""
@@ -174,74 +172,57 @@ class CSMC:
         return 1 / rho
 
     def get_tree_prob(self, vertex_dicts, weights_KxNm1, K):
-        """csmc.py:335-349."""
-        trees = [dic.keys() for dic in vertex_dicts]
-        tree_probabilities = []
-        for i in range(len(trees)):
-            tree = trees[i]
-            tree_probabilities.append(0)
-            for k in range(K):
-                if tree == trees[k]:
-                    tree_probabilities[i] += weights_KxNm1[k, -1]
-            tree_probabilities[i] /= K
-        tree_probabilities /= 1 / K * sum(weights_KxNm1[:, -1])
-        return list(tree_probabilities), trees
+        """csmc.py:335-349: for every particle, the normalised sum of the last-rank weights of the particles
+        holding the same set of vertices."""
+        trees = [d.keys() for d in vertex_dicts]
+        last = np.asarray(weights_KxNm1)[:, -1]
+        total = last.sum() / K
+        probs = [sum(last[k] for k in range(K) if trees[k] == t) / K / total for t in trees]
+        return probs, trees
 
     def compute_norm(self, weights_KxNm1, K):
-        """csmc.py:351-355."""
-        norm = 1
-        for i in range(1, self.n - 1):
-            norm *= 1 / K * sum(weights_KxNm1[:, i])
-        return norm
+        """csmc.py:351-355: product over ranks 1..n-2 of the mean weight."""
+        w = np.asarray(weights_KxNm1)
+        return float(np.prod([w[:, i].sum() / K for i in range(1, self.n - 1)]))
 
     def sample_phylogenies(self, K, resampling=False, showing=True):
-        """csmc.py:357-454 with the per-root likelihoods evaluated on the GPU.  Returns
-        (log_weights[K, n-1], tree_probabilities, norm, selected root Vertex)."""
+        """csmc.py:357-454 with every per-root likelihood evaluated on the GPU.  Same control flow and quirks
+        (weights of rank 0 stay 0; log_likelihood_tilda of a particle is the forest likelihood of a
+        RANDOM particle of the partially updated step; resampling permutes jump chains only).  Returns
+        (log_weights[K, n-1], tree_probabilities, norm, root Vertex of the most probable tree)."""
         n = self.n
-        jump_chain = [{} for i in range(n)]
-        jump_chain[0][0] = self.taxa
-        jump_chain_KxN = np.array([jump_chain] * K)
-        log_weights_KxNm1 = np.zeros([K, n - 1])
-        weights_KxNm1 = np.zeros([K, n - 1]) + 1
-        log_likelihood = np.zeros([K, n - 1])
-        log_likelihood_tilda = np.zeros(K) + 1
-        vertex_dicts = [{} for k in range(K)]
-        for j in range(K):
-            for i in range(n):
-                vertex_dicts[j][self.taxa[i]] = Vertex(id=self.taxa[i], data=self.genome_NxSxA[i])
-        last_root = [None] * K
+        chain0 = [{} for _ in range(n)]
+        chain0[0][0] = self.taxa
+        jump_chain_KxN = np.array([chain0] * K)
+        log_w = np.zeros((K, n - 1))
+        w = np.ones((K, n - 1))
+        forests = [{t: Vertex(id=t, data=self.genome_NxSxA[i]) for i, t in enumerate(self.taxa)} for _ in range(K)]
+        newest = [None] * K
+
+        def forest_loglik(forest):
+            return sum(self.compute_log_conditional_likelihood(v) for v in forest.values() if v.is_root)
+
         for i in range(n - 1):
             if resampling and i > 0:
-                jump_chain_KxN[:, i - 1] = self.resample(log_weights_KxNm1, jump_chain_KxN[:, i - 1], i - 1)
+                jump_chain_KxN[:, i - 1] = self.resample(log_w, jump_chain_KxN[:, i - 1], i - 1)
+            ll_tilda = np.ones(K)
+            qs = np.zeros(K)
             for k in range(K):
                 if i > 0:
-                    log_likelihood_tilda[k] = 0
-                    idx = random.randint(0, K - 1)
-                    for key in vertex_dicts[idx]:
-                        if vertex_dicts[idx][key].is_root:
-                            log_likelihood_tilda[k] += self.compute_log_conditional_likelihood(vertex_dicts[idx][key])
-                particle1, particle2, particle_coalesced, bl1, bl2, q, jump_chain_KxN = \
-                    self.extend_partial_state(jump_chain_KxN, k, i)
-                vertex_dicts[k][particle_coalesced] = Vertex(id=particle_coalesced, data=None)
-                vertex_dicts[k][particle_coalesced].left = vertex_dicts[k][particle1]
-                vertex_dicts[k][particle_coalesced].right = vertex_dicts[k][particle2]
-                vertex_dicts[k][particle_coalesced].left_branch = bl1
-                vertex_dicts[k][particle_coalesced].right_branch = bl2
-                vertex_dicts[k][particle1].is_root = False
-                vertex_dicts[k][particle2].is_root = False
-                last_root[k] = vertex_dicts[k][particle_coalesced]
-            for k in range(K):
-                log_likelihood[k, i] = 0
-                for key in vertex_dicts[k]:
-                    if vertex_dicts[k][key].is_root:
-                        log_likelihood[k, i] += self.compute_log_conditional_likelihood(vertex_dicts[k][key])
-                v = self.overcounting_correct(vertex_dicts[k])
-                if i > 0:
-                    log_weights_KxNm1[k, i] = log_likelihood[k, i] - log_likelihood_tilda[k] + np.log(v) - np.log(q)
-                    weights_KxNm1[k, i] = np.exp(log_weights_KxNm1[k, i])
+                    ll_tilda[k] = forest_loglik(forests[random.randint(0, K - 1)])
+                p1, p2, merged, bl1, bl2, qs[k], jump_chain_KxN = self.extend_partial_state(jump_chain_KxN, k, i)
+                v = Vertex(id=merged, data=None)
+                v.left, v.right, v.left_branch, v.right_branch = forests[k][p1], forests[k][p2], bl1, bl2
+                forests[k][p1].is_root = forests[k][p2].is_root = False
+                forests[k][merged] = newest[k] = v
+            if i > 0:
+                for k in range(K):
+                    log_w[k, i] = forest_loglik(forests[k]) - ll_tilda[k] + np.log(self.overcounting_correct(forests[k])) \
+                        - np.log(qs[k])
+                    w[k, i] = np.exp(log_w[k, i])
             if showing:
                 print('Computation in progress: step ' + str(i + 1))
-        tree_probabilities, trees = self.get_tree_prob(vertex_dicts, weights_KxNm1, K)
-        norm = self.compute_norm(weights_KxNm1, K)
-        selected_idx = tree_probabilities.index(max(tree_probabilities))
-        return log_weights_KxNm1, tree_probabilities, norm, last_root[selected_idx]
+        tree_probabilities, trees = self.get_tree_prob(forests, w, K)
+        norm = self.compute_norm(w, K)
+        best = tree_probabilities.index(max(tree_probabilities))
+        return log_w, tree_probabilities, norm, newest[best]
