@@ -722,9 +722,14 @@ int phylo_sweep_fetch(phylo_ctx* c, double* log_weights, double* log_lik, double
         }
     }
     // log_weights / log_lik are stored with global columns; hand back this rank's columns
-    if (log_weights)
-        HIPCHK(c, hipMemcpy2D(log_weights, Kl * 8, c->d_logw + c->k0, K * 8, Kl * 8, R, hipMemcpyDeviceToHost));
-    if (log_lik) HIPCHK(c, hipMemcpy2D(log_lik, Kl * 8, c->d_ll + c->k0, K * 8, Kl * 8, R, hipMemcpyDeviceToHost));
+    if (Kl == K) {                      // one rank: rows are contiguous
+        if (log_weights) HIPCHK(c, hipMemcpy(log_weights, c->d_logw, R * K * 8, hipMemcpyDeviceToHost));
+        if (log_lik) HIPCHK(c, hipMemcpy(log_lik, c->d_ll, R * K * 8, hipMemcpyDeviceToHost));
+    } else {
+        if (log_weights)
+            HIPCHK(c, hipMemcpy2D(log_weights, Kl * 8, c->d_logw + c->k0, K * 8, Kl * 8, R, hipMemcpyDeviceToHost));
+        if (log_lik) HIPCHK(c, hipMemcpy2D(log_lik, Kl * 8, c->d_ll + c->k0, K * 8, Kl * 8, R, hipMemcpyDeviceToHost));
+    }
     if (lbranch) HIPCHK(c, hipMemcpy(lbranch, c->d_bl, R * Kl * 8, hipMemcpyDeviceToHost));
     if (rbranch) HIPCHK(c, hipMemcpy(rbranch, c->d_br, R * Kl * 8, hipMemcpyDeviceToHost));
     if (merges) HIPCHK(c, hipMemcpy(merges, c->d_merges, R * Kl * 2 * 4, hipMemcpyDeviceToHost));

@@ -415,3 +415,21 @@ def test_lazy_nodes_equal_eager_nodes(monkeypatch):
     assert_bit_equal(out['log_weights'], ref['log_weights'], "lazy default, S=9000")
     assert_bit_equal(ctx.sweep_node(2, 5), ref['nodes'][2, 5], "node")
     ctx.close()
+
+
+def test_interleaved_contexts_are_deterministic(primate):
+    """Three contexts on three streams (the bench's configuration), sweeps in flight together: every repetition
+    of a seed must give the same bits (a race between kernels of different sweeps would show here)."""
+    Q = O.get_Q(O.init_y_q())
+    ctxs = [make_ctx(primate, 1024, Q) for _ in range(3)]
+    ref = {}
+    for rep in range(8):
+        for i, c in enumerate(ctxs):
+            c.sweep_async(100 + (i + rep) % 3)
+        for i, c in enumerate(ctxs):
+            out = c.sweep_fetch()
+            seed = 100 + (i + rep) % 3
+            key = (out['logZ'], out['log_weights'].tobytes(), out['ancestors'].tobytes())
+            assert ref.setdefault(seed, key) == key, "sweep with seed %d changed between repetitions" % seed
+    for c in ctxs:
+        c.close()
