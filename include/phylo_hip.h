@@ -136,7 +136,8 @@ int phylo_sweep_fetch(phylo_ctx* ctx, double* log_weights, double* log_lik, doub
 int phylo_synchronize(phylo_ctx* ctx);
 
 /* Partial-likelihood vector of the node created at rank event r by particle slot k in the last sweep,
- * [S,4] (test surface for the merge kernel inside the sweep). */
+ * [S,4] (test surface for the merge kernel inside the sweep).  After a lazy sweep the missing nodes are
+ * written first; when sharded that step is a collective: every rank must make the call. */
 int phylo_sweep_node(phylo_ctx* ctx, int r, int k, double* out_Sx4);
 
 /* Bit-level probe of the device arithmetic contract: op 0 exp(x), 1 log(x), 2 x/y, 3 fma(x,y,x). */

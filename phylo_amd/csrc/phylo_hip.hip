@@ -55,6 +55,7 @@ struct phylo_ctx {
     double* d_rootll[2] = {nullptr, nullptr};                                   // [K][N]
     int32_t* d_child = nullptr;          // [(N-1)][Kloc][2]: children of every node (kept for lazy materialisation)
     unsigned int* d_mark = nullptr;      // [(N-1)][K]: node is in the pool
+    double* d_chosen_or_sync = nullptr;  // [world] dummy payload of the barrier collective used by lazy nodes when sharded
     int32_t* d_mat_list = nullptr;       // [K] nodes queued for materialisation at the current rank event
     unsigned int* d_mat_count = nullptr; // [(N-1)] one counter per rank event (zeroed with the marks)
     bool last_lazy = false;
@@ -154,7 +155,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->tw_capacity = 0;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
                     c->d_roots[0], c->d_roots[1], c->d_cnt[0], c->d_cnt[1], c->d_child, c->d_merges, c->d_anc,
-                    c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1], (void*)c->d_pool_ptrs, c->d_mark, c->d_mat_list};
+                    c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1], (void*)c->d_pool_ptrs, c->d_mark, c->d_mat_list, c->d_chosen_or_sync};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_pool = c->d_nodell = c->d_bl = c->d_br = c->d_Pmat = c->d_logw = c->d_ll = c->d_aux = c->d_lse = nullptr;
@@ -166,6 +167,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_pool_ptrs = nullptr;
     c->d_mark = nullptr;
     c->d_mat_list = nullptr;
+    c->d_chosen_or_sync = nullptr;
     c->d_mat_count = nullptr;
 }
 
@@ -191,6 +193,7 @@ int alloc_sweep_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_mark, ((R * K + R + 3) & ~(size_t)3)));      // marks, then the per-rank queue counters
     c->d_mat_count = c->d_mark + R * K;
     CHK(dalloc(c, &c->d_mat_list, K));
+    CHK(dalloc(c, &c->d_chosen_or_sync, (size_t)c->world));
     CHK(dalloc(c, &c->d_merges, R * Kl * 2));
     CHK(dalloc(c, &c->d_anc, (R > 0 ? R - 1 : 0) * Kl));
     CHK(dalloc(c, &c->d_cdf[0], K));
@@ -571,7 +574,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     // lazy nodes: dead stores are most of the HBM traffic of the plain sweep (a node is read again only if its
     // creator survives the next resampling).  Needs every reader on this GPU and the plain proposal.
     // Pays when a node is large (HBM-bound merges); on small nodes the extra launch costs more than the stores.
-    const bool lazy_ok = !twist && c->comm.transport == 0 && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES");
+    const bool lazy_ok = !twist && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES");
     const bool lazy = lazy_ok && (S >= 8192 || getenv("PHYLO_LAZY_NODES"));
     int launches = 0;
     const bool fuse_scan = !twist && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
@@ -654,9 +657,13 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
             ++launches;
         }
         if (lazy && r > 0) {
-            hipLaunchKernelGGL(pk_materialize_adopted, dim3(cdiv(S, PK_MAT_TILE), K), dim3(PK_COLS), 0, c->stream, b);
+            hipLaunchKernelGGL(pk_materialize_adopted, dim3(cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
             CHK(launch_check(c, "pk_materialize_adopted"));
             ++launches;
+            if (c->comm.transport != 0) {      // peers read these nodes in place: order them before every rank's merge
+                double* rows[1] = {c->d_chosen_or_sync};
+                CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
+            }
         }
         if (timek)   // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
             hipExtLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
@@ -765,9 +772,13 @@ int phylo_sweep_node(phylo_ctx* c, int r, int k, double* out) {
         b.N = c->N; b.S = c->S; b.K = c->K; b.Kloc = c->Kloc; b.k0 = c->k0;
         b.leaves = c->d_leaves; b.pool = c->d_pool; b.pool_ptrs = c->d_pool_ptrs;
         b.mark = c->d_mark; b.child_all = c->d_child; b.Pmat_all = c->d_Pmat;
-        for (int rho = 0; rho < c->N - 1; ++rho) {
+        for (int rho = 0; rho < c->N - 1; ++rho) {       // sharded: a collective (every rank must call phylo_sweep_node)
             hipLaunchKernelGGL(pk_materialize_rank, dim3(c->Kloc), dim3(PK_COLS), 0, c->stream, b, rho);
             CHK(launch_check(c, "pk_materialize_rank"));
+            if (c->comm.transport != 0) {
+                double* rows[1] = {c->d_chosen_or_sync};
+                CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
+            }
         }
         c->last_lazy = false;
     }

@@ -724,8 +724,9 @@ __global__ __launch_bounds__(64) void pk_rank_book(const pk_rank_args a) {
     if (a.lazy && a.r > 0 && threadIdx.x == 0) {
         // this particle adopted the table of `anc`: the node anc created at the previous rank event is now live.
         // The first adopter queues it for pk_materialize_adopted.
-        const int anc = L.misc[3];
-        if (atomicExch(a.mark + (size_t)(a.r - 1) * a.K + anc, 1u) == 0u) a.mat_list[atomicAdd(a.mat_count, 1u)] = anc;
+        const int anc = L.misc[3];                    // every rank sees every adoption; the OWNER of the node writes it
+        if (atomicExch(a.mark + (size_t)(a.r - 1) * a.K + anc, 1u) == 0u && anc >= a.k0 && anc < a.k0 + a.Kloc)
+            a.mat_list[atomicAdd(a.mat_count, 1u)] = anc;
     }
 }
 
@@ -761,8 +762,9 @@ __global__ __launch_bounds__(PK_COLS) void pk_rank_scan_book(const pk_rank_args 
     if (a.lazy && a.r > 0 && threadIdx.x == 0) {
         // this particle adopted the table of `anc`: the node anc created at the previous rank event is now live.
         // The first adopter queues it for pk_materialize_adopted.
-        const int anc = L.misc[3];
-        if (atomicExch(a.mark + (size_t)(a.r - 1) * a.K + anc, 1u) == 0u) a.mat_list[atomicAdd(a.mat_count, 1u)] = anc;
+        const int anc = L.misc[3];                    // every rank sees every adoption; the OWNER of the node writes it
+        if (atomicExch(a.mark + (size_t)(a.r - 1) * a.K + anc, 1u) == 0u && anc >= a.k0 && anc < a.k0 + a.Kloc)
+            a.mat_list[atomicAdd(a.mat_count, 1u)] = anc;
     }
 }
 

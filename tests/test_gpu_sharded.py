@@ -67,6 +67,25 @@ def test_sharded_sweep_bit_identical(world, K, jc):
     assert (parts[0]['ancestors'] >= Kl).any()
 
 
+def test_sharded_lazy_nodes_bit_identical():
+    """Lazy nodes when sharded: the owner writes an adopted node, a barrier collective orders it before the
+    peers' merges; phylo_sweep_node completes the pool collectively."""
+    world, K, seed = 2, 64, 7
+    parts = run_world(world, K, 'primate_data', seed, False, n_sweeps=2, extra_env={'PHYLO_LAZY_NODES': '1'})
+    g = load_dataset('primate_data')['genome']
+    N = g.shape[0]
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    ref = CO.sweep(g, Q, PI, lam, lam, K, seed + 1, want_nodes=True)
+    Kl = K // world
+    for r, p in enumerate(parts):
+        sl = slice(r * Kl, (r + 1) * Kl)
+        np.testing.assert_array_equal(p['ancestors'], ref['ancestors'][:, sl])
+        assert np.array_equal(p['log_weights'].view(np.uint64), ref['log_weights'][:, sl].view(np.uint64))
+        assert float(p['logZ']) == ref['logZ']
+        assert np.array_equal(p['node'].view(np.uint64), ref['nodes'][N - 2, (r + 1) * Kl - 1].view(np.uint64))
+
+
 def test_rccl_single_rank_world():
     """RCCL communicator with one rank: ncclCommInitRank / grouped in-place all-gather on the real library."""
     parts = run_world(1, 32, 'primate_data_wang', 1, True, transport='rccl', extra_env={'PHYLO_COMM_FORCE_RCCL': '1'})
