@@ -45,7 +45,6 @@ struct phylo_comm {
     std::string shm_name;
     void* shm = nullptr;
     size_t shm_bytes = 0, slot_bytes = 0;
-    std::vector<char> host_tmp;
     // peer pools
     std::vector<void*> peer_base;      // opened IPC mappings (nullptr for self)
 };

@@ -55,7 +55,7 @@ struct phylo_ctx {
     double* d_rootll[2] = {nullptr, nullptr};                                   // [K][N]
     int32_t* d_child = nullptr;          // [(N-1)][Kloc][2]: children of every node (kept for lazy materialisation)
     unsigned int* d_mark = nullptr;      // [(N-1)][K]: node is in the pool
-    double* d_chosen_or_sync = nullptr;  // [world] dummy payload of the barrier collective used by lazy nodes when sharded
+    double* d_sync = nullptr;  // [world] dummy payload of the barrier collective used by lazy nodes when sharded
     int32_t* d_mat_list = nullptr;       // [K] nodes queued for materialisation at the current rank event
     unsigned int* d_mat_count = nullptr; // [(N-1)] one counter per rank event (zeroed with the marks)
     bool last_lazy = false;
@@ -70,7 +70,6 @@ struct phylo_ctx {
     double *d_rootll_ad = nullptr, *d_chosen = nullptr, *d_tw_b = nullptr, *d_tw_P = nullptr, *d_pot = nullptr;
     size_t tw_capacity = 0;              // in (particle, sub-sample) entries
     phylo_stats stats{};
-    uint32_t last_flags = 0;
     int n_merge_events = 0;
     // grow-only scratch for the op-level entry points
     DevBuf scratch[6];
@@ -155,7 +154,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->tw_capacity = 0;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
                     c->d_roots[0], c->d_roots[1], c->d_cnt[0], c->d_cnt[1], c->d_child, c->d_merges, c->d_anc,
-                    c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1], (void*)c->d_pool_ptrs, c->d_mark, c->d_mat_list, c->d_chosen_or_sync};
+                    c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1], (void*)c->d_pool_ptrs, c->d_mark, c->d_mat_list, c->d_sync};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_pool = c->d_nodell = c->d_bl = c->d_br = c->d_Pmat = c->d_logw = c->d_ll = c->d_aux = c->d_lse = nullptr;
@@ -167,7 +166,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_pool_ptrs = nullptr;
     c->d_mark = nullptr;
     c->d_mat_list = nullptr;
-    c->d_chosen_or_sync = nullptr;
+    c->d_sync = nullptr;
     c->d_mat_count = nullptr;
 }
 
@@ -193,7 +192,7 @@ int alloc_sweep_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_mark, ((R * K + R + 3) & ~(size_t)3)));      // marks, then the per-rank queue counters
     c->d_mat_count = c->d_mark + R * K;
     CHK(dalloc(c, &c->d_mat_list, K));
-    CHK(dalloc(c, &c->d_chosen_or_sync, (size_t)c->world));
+    CHK(dalloc(c, &c->d_sync, (size_t)c->world));
     CHK(dalloc(c, &c->d_merges, R * Kl * 2));
     CHK(dalloc(c, &c->d_anc, (R > 0 ? R - 1 : 0) * Kl));
     CHK(dalloc(c, &c->d_cdf[0], K));
@@ -661,7 +660,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
             CHK(launch_check(c, "pk_materialize_adopted"));
             ++launches;
             if (c->comm.transport != 0) {      // peers read these nodes in place: order them before every rank's merge
-                double* rows[1] = {c->d_chosen_or_sync};
+                double* rows[1] = {c->d_sync};
                 CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
             }
         }
@@ -695,7 +694,6 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->swept = true;
     c->last_lazy = lazy;
-    c->last_flags = flags;
     c->n_merge_events = timek ? R : 0;
     c->stats.n_launches = launches;
     c->stats.units = (double)Kl * S * R;
@@ -776,7 +774,7 @@ int phylo_sweep_node(phylo_ctx* c, int r, int k, double* out) {
             hipLaunchKernelGGL(pk_materialize_rank, dim3(c->Kloc), dim3(PK_COLS), 0, c->stream, b, rho);
             CHK(launch_check(c, "pk_materialize_rank"));
             if (c->comm.transport != 0) {
-                double* rows[1] = {c->d_chosen_or_sync};
+                double* rows[1] = {c->d_sync};
                 CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
             }
         }

@@ -135,16 +135,6 @@ __global__ __launch_bounds__(PK_COLS) void pk_row_loglik(const double* __restric
     if (threadIdx.x == 0) out[blockIdx.x] = tot;
 }
 
-// canonical sum of plain values: rows of length n
-__global__ __launch_bounds__(PK_COLS) void pk_row_sum(const double* __restrict__ x, int n, double* __restrict__ out) {
-    __shared__ double sh4[4];
-    const double* row = x + (size_t)blockIdx.x * n;
-    double col = 0.0;
-    for (int s = threadIdx.x; s < n; s += PK_COLS) col = col + row[s];
-    const double tot = pk_block_canon_sum(col, sh4);
-    if (threadIdx.x == 0) out[blockIdx.x] = tot;
-}
-
 // forest posterior tail (vcsmc.py:242-245): out[k] = sum_x rowll[k,x] + sum_x -ldf[record[k,x]]
 __global__ void pk_forest_tail(const double* __restrict__ rowll, const int32_t* __restrict__ record,
                                const double* __restrict__ ldf, int ldf_n, int K, int X, double* __restrict__ out) {
