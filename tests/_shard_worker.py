@@ -27,8 +27,10 @@ def main():
     cid = exchange_comm_id(rank, world, _ffi.comm_unique_id if rank == 0 else None)
     ctx.comm_init(rank, world, cid)
     res = None
+    twist_M = int(os.environ.get('PHYLO_TEST_TWIST_M', '0'))
+    flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if twist_M else 0)
     for s in range(n_sweeps):                     # back-to-back sweeps reuse the node pool slabs
-        res = ctx.sweep(seed + s)
+        res = ctx.sweep(seed + s, flags=flags, M=max(twist_M, 1))
     t = ctx.comm_max(float(rank))
     assert t == world - 1, t
     ctx.comm_barrier()

@@ -86,6 +86,23 @@ def test_sharded_lazy_nodes_bit_identical():
         assert np.array_equal(p['node'].view(np.uint64), ref['nodes'][N - 2, (r + 1) * Kl - 1].view(np.uint64))
 
 
+def test_sharded_twisted_sweep_bit_identical():
+    """Twisting when sharded: potentials are computed for local particles only, the chosen (pair, sub-sample)
+    of every particle travels with one more all-gather, then every rank updates all root tables."""
+    world, K, M, seed = 2, 32, 2, 3
+    parts = run_world(world, K, 'primate_data_wang', seed, True, extra_env={'PHYLO_TEST_TWIST_M': str(M)})
+    g = load_dataset('primate_data_wang')['genome']
+    lam = np.full(8, 10.0)
+    ref = CO.sweep_twisted(g, O.jc_Q(), PI, lam, lam, K, M, seed, jc=True)
+    Kl = K // world
+    for r, p in enumerate(parts):
+        sl = slice(r * Kl, (r + 1) * Kl)
+        np.testing.assert_array_equal(p['ancestors'], ref['ancestors'][:, sl])
+        np.testing.assert_array_equal(p['merges'], ref['merges'][:, sl])
+        assert np.array_equal(p['log_weights'].view(np.uint64), ref['log_weights'][:, sl].view(np.uint64))
+        assert float(p['logZ']) == ref['logZ']
+
+
 def test_rccl_single_rank_world():
     """RCCL communicator with one rank: ncclCommInitRank / grouped in-place all-gather on the real library."""
     parts = run_world(1, 32, 'primate_data_wang', 1, True, transport='rccl', extra_env={'PHYLO_COMM_FORCE_RCCL': '1'})
