@@ -50,6 +50,8 @@ enum {
     PHYLO_EAGER_NODES = 1u << 3,       /* always store every new node's partial likelihoods.  Default: on one GPU, plain
                                           proposal, S >= 8192, only nodes whose creator survives the next resampling
                                           are written (the rest are dead stores); results are identical either way */
+    PHYLO_KEEP_GRAPH = 1u << 4,        /* keep what phylo_sweep_backward needs (root-table history of every rank
+                                          event, every node); one GPU, plain proposal; implies PHYLO_EAGER_NODES */
     PHYLO_FLAGS_DEFAULT = PHYLO_QUIRK_Q1_RAW_Q
 };
 
@@ -139,6 +141,16 @@ int phylo_synchronize(phylo_ctx* ctx);
  * [S,4] (test surface for the merge kernel inside the sweep).  After a lazy sweep the missing nodes are
  * written first; when sharded that step is a collective: every rank must make the call. */
 int phylo_sweep_node(phylo_ctx* ctx, int r, int k, double* out_Sx4);
+
+/* Reverse pass of the last sweep (which must have run with PHYLO_KEEP_GRAPH): the gradient of log Z-hat with
+ * respect to the raw model quantities, d_lam_l[N-1], d_lam_r[N-1], d_pi[4], d_Q[16] (row-major).
+ * Replaces the TensorFlow autodiff behind optimizer.minimize(self.cost), vcsmc.py:488-491,534 (cost = -logZ):
+ * resampling indices, pair picks and gather indices are constants, branch lengths are reparameterised samples
+ * b = -log(U)/lambda (vcsmc.py:353-356), everything else is differentiated.  With jc69_closed_form the Q and pi
+ * outputs are still produced (the reference holds them constant; the host ignores them).
+ * perf (may be NULL): sweep_ms = device time of the reverse pass. */
+int phylo_sweep_backward(phylo_ctx* ctx, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q,
+                         phylo_stats* perf);
 
 /* Bit-level probe of the device arithmetic contract: op 0 exp(x), 1 log(x), 2 x/y, 3 fma(x,y,x). */
 int phylo_math_probe(phylo_ctx* ctx, int op, const double* x, const double* y, int n, double* out);

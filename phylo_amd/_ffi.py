@@ -18,6 +18,7 @@ QUIRK_Q1_RAW_Q = 1 << 0
 TWISTING = 1 << 1
 TIME_KERNELS = 1 << 2
 EAGER_NODES = 1 << 3
+KEEP_GRAPH = 1 << 4
 FLAGS_DEFAULT = QUIRK_Q1_RAW_Q
 COMM_ID_BYTES = 128
 
@@ -25,7 +26,8 @@ EXPORTS = [
     "phylo_version", "phylo_last_error", "phylo_device_count", "phylo_create", "phylo_destroy",
     "phylo_set_leaves", "phylo_set_model", "phylo_expm_batched", "phylo_cond_likelihood_K",
     "phylo_forest_loglik", "phylo_tree_loglik", "phylo_resample", "phylo_log_zsmc", "phylo_sweep",
-    "phylo_sweep_async", "phylo_sweep_fetch", "phylo_synchronize", "phylo_sweep_node", "phylo_math_probe",
+    "phylo_sweep_async", "phylo_sweep_fetch", "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
+    "phylo_math_probe",
     "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_max", "phylo_comm_barrier",
 ]
 
@@ -209,6 +211,16 @@ class Context:
     def sweep_node(self, r, k):
         out = np.empty((self.S, 4))
         self._check(self._lib.phylo_sweep_node(self._h, C.c_int(r), C.c_int(k), _ptr(out)))
+        return out
+
+    def sweep_backward(self):
+        """Gradient of logZ of the last sweep (run with KEEP_GRAPH) w.r.t. lam_l, lam_r, pi, Q (raw quantities)."""
+        R = self.N - 1
+        out = {'d_lam_l': np.empty(R), 'd_lam_r': np.empty(R), 'd_pi': np.empty(4), 'd_Q': np.empty((4, 4))}
+        st = Stats()
+        self._check(self._lib.phylo_sweep_backward(self._h, _ptr(out['d_lam_l']), _ptr(out['d_lam_r']), _ptr(out['d_pi']),
+                                                   _ptr(out['d_Q']), C.byref(st)))
+        out['backward_ms'] = st.sweep_ms
         return out
 
     # ---- multi-GPU

@@ -1,0 +1,393 @@
+// Reverse pass of the sweep: d log Z-hat / d(lam_l, lam_r, pi, Q)  (gfx950).
+//
+// The reference obtains this derivative by TensorFlow autodiff of cost = -log Z-hat through the tf.while_loop
+// of sample_phylogenies (vcsmc.py:445-447, 488-491, 534).  Here it is written out by hand over the node pool
+// the forward sweep already keeps (DESIGN.md "VI step"):
+//   * discrete choices (resampling indices, pair picks, every gather index) are constants;
+//   * branch lengths are reparameterised samples b = -log(U)/lambda (tfp Exponential, vcsmc.py:353-356), so
+//     the gradient reaches the rates through them;
+//   * the expm, the merges, log, logsumexp are differentiated.
+// Accumulation orders are fixed (no floating-point atomics): a gradient is reproducible run to run.
+// Parity: oracle/cpu_grad.py (which is checked against central differences), to a relative 1e-9.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "phylo_math.h"
+
+#define PG_TILE 256                    // sites per workgroup of pg_nodes
+#define PG_PART 36                     // per-(node, tile) partial sums: Pl_bar[16], Pr_bar[16], pi_bar[4]
+#define PG_NODEG 22                    // per-node results: bl_bar, br_bar, Q_bar[16], pi_bar[4]
+#define PG_PCHUNK 8                    // parents staged in LDS at a time
+
+struct pg_args {
+    int N, S, K, R, T, jc;
+    const double* leaves;              // [N][S][4]
+    const double* pool;                // [R][K][S][4]
+    double* adj;                       // [R][K][S][4]: d logZ / d node
+    const double* Pmat;                // [R][K][32]
+    const double *bl, *br;             // [R][K]
+    const double *logw, *lse;          // [R][K], [R] (lse = logsumexp - log K)
+    const double *pi, *Q;              // [4], [16]
+    const double *lam_l, *lam_r;       // [R]
+    const int32_t* child;              // [R][K][2] node ids
+    const int32_t* pos;                // [R][K][N]: slot of the adopted table -> position in the new table, -1 = merged
+    const int32_t* roots;              // [R+1][K][N]: plane r+1 = root table after rank event r
+    const int32_t *ad_off, *ad_idx;    // [R][K+1], [R][K]: adopters of particle k at rank event r, ascending
+    const int32_t *par_off, *par_idx;  // [R K + 1], [<= 2 R K]: parents of internal node x, (node * 2 + side), ascending
+    double *om, *G;                    // [R][K]
+    double* C;                         // [R][K][N]: coefficient of sum_s log(pi . X) of every root slot after rank event r
+    double* part;                      // [R][K][T][PG_PART]
+    double* nodeg;                     // [R][K][PG_NODEG]
+    double* leafpi;                    // [N][4]: sum_s leaf[s][a] / (pi . leaf[s])
+    double* leafterm;                  // [K][4]
+    double* terms;                     // [R][K][2]
+    double* out;                       // [2 R + 20]: d_lam_l, d_lam_r, d_pi, d_Q
+};
+
+// ---- small helpers ------------------------------------------------------------------------------
+__device__ __forceinline__ double pg_wave_sum(double v) {          // fixed butterfly: same result on every lane
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+// sum of `v` over the 256 threads of the workgroup, result valid on thread 0 (fixed order)
+__device__ __forceinline__ double pg_block_sum(double v, double* sh /*[4]*/) {
+    v = pg_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+__device__ __forceinline__ const double* pg_row(const pg_args& a, int id) {
+    return id < a.N ? a.leaves + (size_t)id * a.S * 4 : a.pool + (size_t)(id - a.N) * a.S * 4;
+}
+
+// Frechet derivative of the matrix exponential, L(A, E) = d/dt exp(A + t E) at t = 0, by a scaled Taylor
+// series on the pair (X, dX) (the blocks of exp [[A, E], [0, A]]) and pairwise squaring.  ||A||_1 <= 1/2 after
+// scaling and 18 terms leave a truncation error below 1e-22.
+__device__ inline void pg_expm4_frechet(const double* A0, const double* E0, double* Lout) {
+    double A[16], E[16], X[16], D[16], SX[16], SD[16], T1[16], T2[16];
+    double norm = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double cs = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs = cs + (A0[i * 4 + j] < 0.0 ? -A0[i * 4 + j] : A0[i * 4 + j]);
+        if (cs > norm) norm = cs;
+    }
+    int s = 0;
+    double lim = 0.5;
+    while (norm > lim && s < 60) { lim = lim * 2.0; ++s; }
+    const double sc = pm_from_bits((uint64_t)(1023 - s) << 52);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        A[i] = A0[i] * sc;
+        E[i] = E0[i] * sc;
+        const double id = (i % 5 == 0) ? 1.0 : 0.0;
+        X[i] = id; D[i] = 0.0;                 // term 0
+        SX[i] = id; SD[i] = 0.0;
+    }
+#pragma unroll 1
+    for (int k = 1; k <= 18; ++k) {
+        const double inv = 1.0 / (double)k;
+        pm_mm4(X, E, T1);                      // D_k = (X_{k-1} E + D_{k-1} A) / k
+        pm_mm4(D, A, T2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) D[i] = (T1[i] + T2[i]) * inv;
+        pm_mm4(X, A, T1);                      // X_k = X_{k-1} A / k
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            X[i] = T1[i] * inv;
+            SX[i] = SX[i] + X[i];
+            SD[i] = SD[i] + D[i];
+        }
+    }
+#pragma unroll 1
+    for (int q = 0; q < s; ++q) {              // (R, dR) <- (R R, R dR + dR R)
+        pm_mm4(SX, SD, T1);
+        pm_mm4(SD, SX, T2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) SD[i] = T1[i] + T2[i];
+        pm_mm4(SX, SX, T1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) SX[i] = T1[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Lout[i] = SD[i];
+}
+
+// ---- g1: omega = softmax_k(log w_r) ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void pg_omega(pg_args a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.R * a.K) return;
+    const int r = t / a.K;
+    a.om[t] = pm_exp((a.logw[t] - a.lse[r]) - pm_log((double)a.K));
+}
+
+// ---- g2: G_r[k] = d logZ / d ll_r[k] = omega_r[k] - sum of omega_{r+1} over the particles that adopt k -----
+__global__ __launch_bounds__(256) void pg_G(pg_args a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.R * a.K) return;
+    const int r = t / a.K, k = t - r * a.K;
+    double g = a.om[t];
+    if (r + 1 < a.R) {
+        const int32_t* off = a.ad_off + (size_t)(r + 1) * (a.K + 1);
+        const int32_t* idx = a.ad_idx + (size_t)(r + 1) * a.K;
+        double sub = 0.0;
+        for (int j = off[k]; j < off[k + 1]; ++j) sub = sub + a.om[(size_t)(r + 1) * a.K + idx[j]];
+        g = g - sub;
+    }
+    a.G[t] = g;
+}
+
+// ---- g3: root-slot coefficients, one rank event per launch (newest first); one wave per particle ----------
+// C_r[k][slot] = G_r[k] + sum over adopters k' of C_{r+1}[k'][position of that slot in k''s new table]
+__global__ __launch_bounds__(64) void pg_coeff(pg_args a, int r) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const int n1 = a.N - r - 1;
+    const double g = a.G[(size_t)r * a.K + k];
+    double* Ck = a.C + ((size_t)r * a.K + k) * a.N;
+    int off = 0, cnt = 0;
+    if (r + 1 < a.R) {
+        const int32_t* o = a.ad_off + (size_t)(r + 1) * (a.K + 1);
+        off = o[k];
+        cnt = o[k + 1] - off;
+    }
+    if (cnt == 0) {
+        for (int s = lane; s < n1; s += 64) Ck[s] = g;
+        return;
+    }
+    const int32_t* idx = a.ad_idx + (size_t)(r + 1) * a.K + off;
+    const size_t base = (size_t)(r + 1) * a.K;
+#pragma unroll 1
+    for (int slot = 0; slot < n1; ++slot) {
+        double v = 0.0;
+        for (int j = lane; j < cnt; j += 64) {
+            const size_t row = (base + idx[j]) * a.N;
+            const int p = a.pos[row + slot];
+            if (p >= 0) v = v + a.C[row + p];
+        }
+        v = pg_wave_sum(v);
+        if (lane == 0) Ck[slot] = g + v;
+    }
+}
+
+// ---- g4: per-leaf sums for d/d pi of the leaf terms -----------------------------------------------------
+__global__ __launch_bounds__(256) void pg_leafpi(pg_args a) {
+    __shared__ double sh[4];
+    const int x = blockIdx.x;
+    const double* row = a.leaves + (size_t)x * a.S * 4;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int s = threadIdx.x; s < a.S; s += 256) {
+        const double l0 = row[s * 4], l1 = row[s * 4 + 1], l2 = row[s * 4 + 2], l3 = row[s * 4 + 3];
+        const double lik = ((a.pi[0] * l0 + a.pi[1] * l1) + a.pi[2] * l2) + a.pi[3] * l3;
+        const double inv = 1.0 / lik;
+        acc[0] = acc[0] + l0 * inv; acc[1] = acc[1] + l1 * inv; acc[2] = acc[2] + l2 * inv; acc[3] = acc[3] + l3 * inv;
+    }
+    for (int q = 0; q < 4; ++q) {
+        const double t = pg_block_sum(acc[q], sh);
+        if (threadIdx.x == 0) a.leafpi[x * 4 + q] = t;
+    }
+}
+
+// leaves that still are roots after rank event 0 enter ll through pi . leaf[s]
+__global__ __launch_bounds__(256) void pg_leafterm(pg_args a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.K) return;
+    const int32_t* tab = a.roots + ((size_t)1 * a.K + k) * a.N;
+    const double* Ck = a.C + (size_t)k * a.N;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int p = 0; p < a.N - 1; ++p) {
+        const int x = tab[p];
+        if (x < a.N) {
+            const double c = Ck[p];
+            for (int q = 0; q < 4; ++q) acc[q] = acc[q] + c * a.leafpi[x * 4 + q];
+        }
+    }
+    for (int q = 0; q < 4; ++q) a.leafterm[k * 4 + q] = acc[q];
+}
+
+// ---- g5: node adjoints of one rank event (newest first) ---------------------------------------------------
+// grid (tiles, K); thread per site.  Xbar = alpha pi / (pi . X) + sum over parents (Xbar_parent o (sib P_sib)) P_me^T;
+// then the contributions of this node's own merge to Pl_bar, Pr_bar and of its likelihood term to pi_bar.
+__global__ __launch_bounds__(PG_TILE) void pg_nodes(pg_args a, int r) {
+    __shared__ double shP[PG_PCHUNK][32];
+    __shared__ int shE[PG_PCHUNK];
+    __shared__ int shSib[PG_PCHUNK];
+    __shared__ double shR[4][PG_PART];
+    const int k = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int s = tile * PG_TILE + tid;
+    const bool live = s < a.S;
+    const size_t node = (size_t)r * a.K + k;
+    const size_t row = (size_t)a.S * 4;
+    const double alpha = a.C[node * a.N + (a.N - r - 2)];
+    const double p0 = a.pi[0], p1 = a.pi[1], p2 = a.pi[2], p3 = a.pi[3];
+    double xb[4] = {0.0, 0.0, 0.0, 0.0}, dpi[4] = {0.0, 0.0, 0.0, 0.0};
+    if (live) {
+        const double* x = a.pool + node * row + (size_t)s * 4;
+        const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+        const double lik = ((p0 * x0 + p1 * x1) + p2 * x2) + p3 * x3;
+        const double inv = alpha / lik;
+        xb[0] = p0 * inv; xb[1] = p1 * inv; xb[2] = p2 * inv; xb[3] = p3 * inv;
+        dpi[0] = x0 * inv; dpi[1] = x1 * inv; dpi[2] = x2 * inv; dpi[3] = x3 * inv;
+    }
+    const int pbeg = a.par_off[node], pend = a.par_off[node + 1];
+    for (int c0 = pbeg; c0 < pend; c0 += PG_PCHUNK) {
+        const int nc = (pend - c0) < PG_PCHUNK ? (pend - c0) : PG_PCHUNK;
+        __syncthreads();
+        {
+            const int e = tid >> 5, q = tid & 31;
+            if (e < nc) {
+                const int enc = a.par_idx[c0 + e];
+                const int pn = enc >> 1, side = enc & 1;
+                shP[e][q] = a.Pmat[(size_t)pn * 32 + q];
+                if (q == 0) { shE[e] = enc; shSib[e] = a.child[(size_t)pn * 2 + (1 - side)]; }
+            }
+        }
+        __syncthreads();
+        if (live) {
+            for (int e = 0; e < nc; ++e) {
+                const int enc = shE[e];
+                const int pn = enc >> 1, side = enc & 1;
+                const double* xp = a.adj + (size_t)pn * row + (size_t)s * 4;
+                const double* sb = pg_row(a, shSib[e]) + (size_t)s * 4;
+                const double* Psib = shP[e] + (1 - side) * 16;
+                const double* Pme = shP[e] + side * 16;
+                const double b0 = sb[0], b1 = sb[1], b2 = sb[2], b3 = sb[3];
+                double t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double w = ((b0 * Psib[j] + b1 * Psib[4 + j]) + b2 * Psib[8 + j]) + b3 * Psib[12 + j];
+                    t[j] = xp[j] * w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    xb[i] = xb[i] + (((t[0] * Pme[i * 4] + t[1] * Pme[i * 4 + 1]) + t[2] * Pme[i * 4 + 2]) + t[3] * Pme[i * 4 + 3]);
+            }
+        }
+    }
+    double acc[PG_PART];
+#pragma unroll
+    for (int q = 0; q < PG_PART; ++q) acc[q] = 0.0;
+    if (live) {
+        double* o = a.adj + node * row + (size_t)s * 4;
+        o[0] = xb[0]; o[1] = xb[1]; o[2] = xb[2]; o[3] = xb[3];
+        const int cl = a.child[node * 2], cr = a.child[node * 2 + 1];
+        const double* Lr = pg_row(a, cl) + (size_t)s * 4;
+        const double* Rr = pg_row(a, cr) + (size_t)s * 4;
+        const double* Pl = a.Pmat + node * 32;
+        const double* Pr = Pl + 16;
+        const double L[4] = {Lr[0], Lr[1], Lr[2], Lr[3]}, Rv[4] = {Rr[0], Rr[1], Rr[2], Rr[3]};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double u = ((L[0] * Pl[j] + L[1] * Pl[4 + j]) + L[2] * Pl[8 + j]) + L[3] * Pl[12 + j];
+            const double v = ((Rv[0] * Pr[j] + Rv[1] * Pr[4 + j]) + Rv[2] * Pr[8 + j]) + Rv[3] * Pr[12 + j];
+            const double tl = xb[j] * v, tr = xb[j] * u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i * 4 + j] = L[i] * tl;
+                acc[16 + i * 4 + j] = Rv[i] * tr;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[32 + q] = dpi[q];
+    }
+#pragma unroll
+    for (int q = 0; q < PG_PART; ++q) {
+        const double v = pg_wave_sum(acc[q]);
+        if ((tid & 63) == 0) shR[tid >> 6][q] = v;
+    }
+    __syncthreads();
+    if (tid < PG_PART)
+        a.part[(node * a.T + tile) * PG_PART + tid] = ((shR[0][tid] + shR[1][tid]) + shR[2][tid]) + shR[3][tid];
+}
+
+// ---- g6: per node: tiles -> Pl_bar, Pr_bar -> branch adjoints and the Q adjoint ----------------------------
+__global__ __launch_bounds__(64) void pg_node_finish(pg_args a) {
+    const size_t node = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= (size_t)a.R * a.K) return;
+    double pb[PG_PART];
+#pragma unroll
+    for (int q = 0; q < PG_PART; ++q) pb[q] = 0.0;
+    for (int t = 0; t < a.T; ++t) {
+        const double* p = a.part + (node * a.T + t) * PG_PART;
+#pragma unroll
+        for (int q = 0; q < PG_PART; ++q) pb[q] = pb[q] + p[q];
+    }
+    double Q[16], QP[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Q[i] = a.Q[i];
+    double* out = a.nodeg + node * PG_NODEG;
+    double dQ[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dQ[i] = 0.0;
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const double* P = a.Pmat + node * 32 + side * 16;
+        double Pm[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Pm[i] = P[i];
+        pm_mm4(Q, Pm, QP);                                   // dP/db = Q P
+        double bb = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bb = bb + pb[side * 16 + i] * QP[i];
+        out[side] = bb;
+        if (!a.jc) {                                         // <Pbar, L(Qb, E b)> = <b L((Qb)^T, Pbar), E>
+            const double b = (side ? a.br : a.bl)[node];
+            double At[16], Eb[16], Lf[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { At[i * 4 + j] = Q[j * 4 + i] * b; Eb[i * 4 + j] = pb[side * 16 + i * 4 + j]; }
+            pg_expm4_frechet(At, Eb, Lf);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dQ[i] = dQ[i] + b * Lf[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[2 + i] = dQ[i];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[18 + q] = pb[32 + q];
+}
+
+// ---- g7: explicit occurrences of b and lambda in ll_r and in the proposal term; pathwise db/dlambda ---------
+__global__ __launch_bounds__(256) void pg_scalars(pg_args a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.R * a.K) return;
+    const int r = t / a.K, k = t - r * a.K;
+    const double om = a.om[t], g = a.G[t];
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const double* lam = side ? a.lam_r : a.lam_l;
+        const double* b = side ? a.br : a.bl;
+        double suffix = 0.0, prefix = 0.0;
+        for (int j = r; j < a.R; ++j) suffix = suffix + a.G[(size_t)j * a.K + k] * lam[j];
+        for (int j = 0; j <= r; ++j) prefix = prefix + b[(size_t)j * a.K + k];
+        const double lr = lam[r], br_ = b[t];
+        const double bbar = (a.nodeg[(size_t)t * PG_NODEG + side] - suffix) + om * lr;
+        a.terms[(size_t)t * 2 + side] = (g * ((double)(r + 1) / lr - prefix) - om * (1.0 / lr - br_)) + bbar * (-br_ / lr);
+    }
+}
+
+// ---- g8: final sums (fixed order): block o < 2R: d_lam; then d_pi[4], d_Q[16] -------------------------------
+__global__ __launch_bounds__(256) void pg_reduce(pg_args a) {
+    __shared__ double sh[4];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    double acc = 0.0;
+    if (o < 2 * a.R) {
+        const int side = o / a.R, r = o - side * a.R;
+        for (int k = tid; k < a.K; k += 256) acc = acc + a.terms[((size_t)r * a.K + k) * 2 + side];
+    } else {
+        const int q = o - 2 * a.R;                           // 0..3 pi, 4..19 Q
+        const int col = q < 4 ? 18 + q : 2 + (q - 4);
+        const size_t n = (size_t)a.R * a.K;
+        for (size_t i = tid; i < n; i += 256) acc = acc + a.nodeg[i * PG_NODEG + col];
+        if (q < 4)
+            for (int k = tid; k < a.K; k += 256) acc = acc + a.leafterm[k * 4 + q];
+    }
+    const double t = pg_block_sum(acc, sh);
+    if (tid == 0) a.out[o] = t;
+}

@@ -14,6 +14,7 @@
 
 #include "phylo_comm.h"
 #include "phylo_kernels.h"
+#include "phylo_grad.h"
 
 namespace {
 
@@ -69,6 +70,14 @@ struct phylo_ctx {
     int32_t *d_roots_ad = nullptr, *d_cnt_ad = nullptr;
     double *d_rootll_ad = nullptr, *d_chosen = nullptr, *d_tw_b = nullptr, *d_tw_P = nullptr, *d_pot = nullptr;
     size_t tw_capacity = 0;              // in (particle, sub-sample) entries
+    // graph kept for the reverse pass (PHYLO_KEEP_GRAPH; allocated on first use)
+    int32_t *d_hroots = nullptr, *d_hcnt = nullptr, *d_pos = nullptr;   // [(R+1)][K][N], [(R+1)][K][N], [R][K][N]
+    double* d_hrootll = nullptr;         // [(R+1)][K][N]
+    double *d_adj = nullptr, *d_om = nullptr, *d_G = nullptr, *d_C = nullptr, *d_part = nullptr, *d_nodeg = nullptr;
+    double *d_leafpi = nullptr, *d_leafterm = nullptr, *d_terms = nullptr, *d_gout = nullptr;
+    int32_t *d_ad_off = nullptr, *d_ad_idx = nullptr, *d_par_off = nullptr, *d_par_idx = nullptr;
+    bool graph_ready = false, last_graph = false;
+    hipEvent_t evb0 = nullptr, evb1 = nullptr;
     phylo_stats stats{};
     int n_merge_events = 0;
     // grow-only scratch for the op-level entry points
@@ -152,6 +161,16 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_roots_ad = c->d_cnt_ad = nullptr;
     c->d_rootll_ad = c->d_chosen = c->d_tw_b = c->d_tw_P = c->d_pot = nullptr;
     c->tw_capacity = 0;
+    void* gr[] = {c->d_hroots, c->d_hcnt, c->d_pos, c->d_hrootll, c->d_adj, c->d_om, c->d_G, c->d_C, c->d_part, c->d_nodeg,
+                  c->d_leafpi, c->d_leafterm, c->d_terms, c->d_gout, c->d_ad_off, c->d_ad_idx, c->d_par_off, c->d_par_idx};
+    for (void* p : gr)
+        if (p) (void)hipFree(p);
+    c->d_hroots = c->d_hcnt = c->d_pos = nullptr;
+    c->d_hrootll = c->d_adj = c->d_om = c->d_G = c->d_C = c->d_part = c->d_nodeg = nullptr;
+    c->d_leafpi = c->d_leafterm = c->d_terms = c->d_gout = nullptr;
+    c->d_ad_off = c->d_ad_idx = c->d_par_off = c->d_par_idx = nullptr;
+    c->graph_ready = false;
+    c->last_graph = false;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
                     c->d_roots[0], c->d_roots[1], c->d_cnt[0], c->d_cnt[1], c->d_child, c->d_merges, c->d_anc,
                     c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1], (void*)c->d_pool_ptrs, c->d_mark, c->d_mat_list, c->d_sync};
@@ -213,6 +232,37 @@ int alloc_sweep_state(phylo_ctx* c) {
 int ensure_sweep_state(phylo_ctx* c) {
     if (c->state_ready) return PHYLO_OK;
     return alloc_sweep_state(c);
+}
+
+// buffers of the reverse pass: table history, adjoint pool, coefficient tables, CSR lists
+int ensure_graph_state(phylo_ctx* c) {
+    if (c->graph_ready) return PHYLO_OK;
+    const size_t R = (size_t)c->N - 1, K = c->K, N = c->N, S = c->S;
+    const size_t T = (S + PG_TILE - 1) / PG_TILE;
+    CHK(dalloc(c, &c->d_hroots, (R + 1) * K * N));
+    CHK(dalloc(c, &c->d_hcnt, (R + 1) * K * N));
+    CHK(dalloc(c, &c->d_hrootll, (R + 1) * K * N));
+    CHK(dalloc(c, &c->d_pos, R * K * N));
+    CHK(dalloc(c, &c->d_adj, R * K * S * 4));
+    CHK(dalloc(c, &c->d_om, R * K));
+    CHK(dalloc(c, &c->d_G, R * K));
+    CHK(dalloc(c, &c->d_C, R * K * N));
+    CHK(dalloc(c, &c->d_part, R * K * T * PG_PART));
+    CHK(dalloc(c, &c->d_nodeg, R * K * PG_NODEG));
+    CHK(dalloc(c, &c->d_leafpi, N * 4));
+    CHK(dalloc(c, &c->d_leafterm, K * 4));
+    CHK(dalloc(c, &c->d_terms, R * K * 2));
+    CHK(dalloc(c, &c->d_gout, 2 * R + 20));
+    CHK(dalloc(c, &c->d_ad_off, R * (K + 1)));
+    CHK(dalloc(c, &c->d_ad_idx, R * K));
+    CHK(dalloc(c, &c->d_par_off, R * K + 1));
+    CHK(dalloc(c, &c->d_par_idx, 2 * R * K));
+    if (!c->evb0) {
+        HIPCHK(c, hipEventCreate(&c->evb0));
+        HIPCHK(c, hipEventCreate(&c->evb1));
+    }
+    c->graph_ready = true;
+    return PHYLO_OK;
 }
 
 // leaf node log-likelihoods sum_s log(pi . leaf[s]) (depend on pi and the leaves)
@@ -299,6 +349,8 @@ int phylo_destroy(phylo_ctx* c) {
     for (hipEvent_t e : c->kev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->evb0) (void)hipEventDestroy(c->evb0);
+    if (c->evb1) (void)hipEventDestroy(c->evb1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PHYLO_OK;
@@ -573,10 +625,16 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     // lazy nodes: dead stores are most of the HBM traffic of the plain sweep (a node is read again only if its
     // creator survives the next resampling).  Needs every reader on this GPU and the plain proposal.
     // Pays when a node is large (HBM-bound merges); on small nodes the extra launch costs more than the stores.
-    const bool lazy_ok = !twist && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES");
+    const bool graph = (flags & PHYLO_KEEP_GRAPH) != 0;
+    if (graph) {
+        if (twist) return fail(c, PHYLO_EINVAL, "PHYLO_KEEP_GRAPH needs the plain proposal (no PHYLO_TWISTING)");
+        if (c->world != 1) return fail(c, PHYLO_EINVAL, "PHYLO_KEEP_GRAPH needs an unsharded context");
+        CHK(ensure_graph_state(c));
+    }
+    const bool lazy_ok = !twist && !graph && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES");
     const bool lazy = lazy_ok && (S >= 8192 || getenv("PHYLO_LAZY_NODES"));
     int launches = 0;
-    const bool fuse_scan = !twist && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
+    const bool fuse_scan = !twist && !graph && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
     const size_t lds = pk_book_lds_bytes(N);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (lazy) HIPCHK(c, hipMemsetAsync(c->d_mark, 0, (((size_t)R * K + R + 3) & ~(size_t)3) * sizeof(unsigned int), c->stream));
@@ -585,8 +643,10 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
                            c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat);
         CHK(launch_check(c, "pk_sweep_draws"));
     }
-    hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream, c->d_roots[0], c->d_cnt[0],
-                       c->d_rootll[0], (const double*)c->d_nodell, K, N);
+    const size_t plane = (size_t)K * N;
+    hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream,
+                       graph ? c->d_hroots : c->d_roots[0], graph ? c->d_hcnt : c->d_cnt[0],
+                       graph ? c->d_hrootll : c->d_rootll[0], (const double*)c->d_nodell, K, N);
     CHK(launch_check(c, "pk_init_tables"));
     launches += 2;
     const double ll_tilde0 = pm_log(1.0 / (double)K);      // vcsmc.py:422
@@ -595,9 +655,16 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         pk_rank_args b{};
         b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
         b.seed = seed; b.flags = flags;
-        b.roots_old = c->d_roots[cur]; b.cnt_old = c->d_cnt[cur];
-        b.roots_new = c->d_roots[nxt]; b.cnt_new = c->d_cnt[nxt];
-        b.rootll_old = c->d_rootll[cur]; b.rootll_new = c->d_rootll[nxt];
+        if (graph) {                                       // every rank event keeps its tables: plane r -> plane r + 1
+            b.roots_old = c->d_hroots + plane * r; b.cnt_old = c->d_hcnt + plane * r;
+            b.roots_new = c->d_hroots + plane * (r + 1); b.cnt_new = c->d_hcnt + plane * (r + 1);
+            b.rootll_old = c->d_hrootll + plane * r; b.rootll_new = c->d_hrootll + plane * (r + 1);
+            b.pos_hist = c->d_pos + plane * r;
+        } else {
+            b.roots_old = c->d_roots[cur]; b.cnt_old = c->d_cnt[cur];
+            b.roots_new = c->d_roots[nxt]; b.cnt_new = c->d_cnt[nxt];
+            b.rootll_old = c->d_rootll[cur]; b.rootll_new = c->d_rootll[nxt];
+        }
         b.cdf = c->d_cdf[cur];
         b.ll_prev = r > 0 ? c->d_ll + (size_t)(r - 1) * K : nullptr;
         b.nodell = c->d_nodell;
@@ -694,6 +761,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->swept = true;
     c->last_lazy = lazy;
+    c->last_graph = graph;
     c->n_merge_events = timek ? R : 0;
     c->stats.n_launches = launches;
     c->stats.units = (double)Kl * S * R;
@@ -783,6 +851,93 @@ int phylo_sweep_node(phylo_ctx* c, int r, int k, double* out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t node_sz = (size_t)c->S * 4;
     HIPCHK(c, hipMemcpy(out, c->d_pool + ((size_t)r * c->Kloc + k) * node_sz, node_sz * 8, hipMemcpyDeviceToHost));
+    return PHYLO_OK;
+}
+
+int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q, phylo_stats* perf) {
+    CHK(bind(c));
+    if (!c->swept || !c->last_graph)
+        return fail(c, PHYLO_ESTATE, "phylo_sweep_backward needs a preceding sweep with PHYLO_KEEP_GRAPH");
+    const int N = c->N, K = c->K, S = c->S, R = N - 1;
+    const int T = (S + PG_TILE - 1) / PG_TILE;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // integer bookkeeping of the reverse pass: who adopted whom, and which nodes have which parents
+    std::vector<int64_t> anc((size_t)(R > 1 ? R - 1 : 0) * K);
+    std::vector<int32_t> child((size_t)R * K * 2);
+    if (R > 1) HIPCHK(c, hipMemcpy(anc.data(), c->d_anc, anc.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(child.data(), c->d_child, child.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int32_t> ad_off((size_t)R * (K + 1), 0), ad_idx((size_t)R * K, 0);
+    for (int r = 1; r < R; ++r) {                          // counting sort by ancestor; ties keep ascending k'
+        int32_t* off = ad_off.data() + (size_t)r * (K + 1);
+        const int64_t* a = anc.data() + (size_t)(r - 1) * K;
+        for (int k = 0; k < K; ++k) ++off[a[k] + 1];
+        for (int k = 0; k < K; ++k) off[k + 1] += off[k];
+        std::vector<int32_t> cur(off, off + K);
+        int32_t* idx = ad_idx.data() + (size_t)r * K;
+        for (int k = 0; k < K; ++k) idx[cur[a[k]]++] = k;
+    }
+    const size_t nn = (size_t)R * K;
+    std::vector<int32_t> par_off(nn + 1, 0), par_idx(2 * nn, 0);
+    for (size_t e = 0; e < 2 * nn; ++e)
+        if (child[e] >= N) ++par_off[(size_t)(child[e] - N) + 1];
+    for (size_t i = 0; i < nn; ++i) par_off[i + 1] += par_off[i];
+    {
+        std::vector<int32_t> cur(par_off.begin(), par_off.end() - 1);
+        for (size_t e = 0; e < 2 * nn; ++e)                // e = node * 2 + side, ascending
+            if (child[e] >= N) par_idx[cur[child[e] - N]++] = (int32_t)e;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ad_off, ad_off.data(), ad_off.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ad_idx, ad_idx.data(), ad_idx.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_par_off, par_off.data(), par_off.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_par_idx, par_idx.data(), par_idx.size() * 4, hipMemcpyHostToDevice, c->stream));
+    pg_args g{};
+    g.N = N; g.S = S; g.K = K; g.R = R; g.T = T; g.jc = c->jc;
+    g.leaves = c->d_leaves; g.pool = c->d_pool; g.adj = c->d_adj; g.Pmat = c->d_Pmat;
+    g.bl = c->d_bl; g.br = c->d_br; g.logw = c->d_logw; g.lse = c->d_lse;
+    g.pi = c->d_pi; g.Q = c->d_Q; g.lam_l = c->d_lam_l; g.lam_r = c->d_lam_r;
+    g.child = c->d_child; g.pos = c->d_pos; g.roots = c->d_hroots;
+    g.ad_off = c->d_ad_off; g.ad_idx = c->d_ad_idx; g.par_off = c->d_par_off; g.par_idx = c->d_par_idx;
+    g.om = c->d_om; g.G = c->d_G; g.C = c->d_C; g.part = c->d_part; g.nodeg = c->d_nodeg;
+    g.leafpi = c->d_leafpi; g.leafterm = c->d_leafterm; g.terms = c->d_terms; g.out = c->d_gout;
+    HIPCHK(c, hipEventRecord(c->evb0, c->stream));
+    const int nrk = cdiv((long)R * K, 256);
+    hipLaunchKernelGGL(pg_omega, dim3(nrk), dim3(256), 0, c->stream, g);
+    CHK(launch_check(c, "pg_omega"));
+    hipLaunchKernelGGL(pg_G, dim3(nrk), dim3(256), 0, c->stream, g);
+    CHK(launch_check(c, "pg_G"));
+    for (int r = R - 1; r >= 0; --r) {
+        hipLaunchKernelGGL(pg_coeff, dim3(K), dim3(64), 0, c->stream, g, r);
+        CHK(launch_check(c, "pg_coeff"));
+    }
+    hipLaunchKernelGGL(pg_leafpi, dim3(N), dim3(256), 0, c->stream, g);
+    CHK(launch_check(c, "pg_leafpi"));
+    hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
+    CHK(launch_check(c, "pg_leafterm"));
+    for (int r = R - 1; r >= 0; --r) {
+        hipLaunchKernelGGL(pg_nodes, dim3(T, K), dim3(PG_TILE), 0, c->stream, g, r);
+        CHK(launch_check(c, "pg_nodes"));
+    }
+    hipLaunchKernelGGL(pg_node_finish, dim3(cdiv((long)R * K, 64)), dim3(64), 0, c->stream, g);
+    CHK(launch_check(c, "pg_node_finish"));
+    hipLaunchKernelGGL(pg_scalars, dim3(nrk), dim3(256), 0, c->stream, g);
+    CHK(launch_check(c, "pg_scalars"));
+    hipLaunchKernelGGL(pg_reduce, dim3(2 * R + 20), dim3(256), 0, c->stream, g);
+    CHK(launch_check(c, "pg_reduce"));
+    HIPCHK(c, hipEventRecord(c->evb1, c->stream));
+    std::vector<double> out((size_t)2 * R + 20);
+    HIPCHK(c, hipMemcpyAsync(out.data(), c->d_gout, out.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (d_lam_l) memcpy(d_lam_l, out.data(), (size_t)R * 8);
+    if (d_lam_r) memcpy(d_lam_r, out.data() + R, (size_t)R * 8);
+    if (d_pi) memcpy(d_pi, out.data() + 2 * R, 4 * 8);
+    if (d_Q) memcpy(d_Q, out.data() + 2 * R + 4, 16 * 8);
+    if (perf) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->evb0, c->evb1));
+        *perf = c->stats;
+        perf->sweep_ms = ms;
+        perf->n_launches = 2 * R + 7;
+    }
     return PHYLO_OK;
 }
 

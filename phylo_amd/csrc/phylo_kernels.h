@@ -470,6 +470,7 @@ struct pk_rank_args {
     const double* Pmat_all;                               // [R][Kloc][32]
     int32_t* child;                                       // [Kloc][2] (row r of child_all): node ids merged at this rank event
     double* aux;                                          // [Kloc][PK_AUX]: weight terms for the merge epilogue
+    int32_t* pos_hist;                                    // [K][N] or NULL (PHYLO_KEEP_GRAPH): adopted slot -> new position, -1 = merged
 };
 
 // LDS carve of the bookkeeping prologue (arrays of length N rounded up to a multiple of 4)
@@ -603,6 +604,7 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
             rn[rank] = node;
             cn[rank] = c;
             rln[rank] = xll;
+            if (a.pos_hist) a.pos_hist[(size_t)kg * N + i] = rank;
             L.ord_cnt[rank] = c;
             L.ord_ll[rank] = xll;
             L.ord_ldf[rank] = L.ldf[c < a.ldf_n ? c : a.ldf_n];
@@ -615,6 +617,7 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
             L.ord_ldf[n - 2] = L.ldf[cnew < a.ldf_n ? cnew : a.ldf_n];
             L.misc[0] = L.ro[il];
             L.misc[1] = L.ro[ir];
+            if (a.pos_hist) { a.pos_hist[(size_t)kg * N + il] = -1; a.pos_hist[(size_t)kg * N + ir] = -1; }
             if (local) {
                 a.merges[((size_t)a.r * a.Kloc + k) * 2 + 0] = il;
                 a.merges[((size_t)a.r * a.Kloc + k) * 2 + 1] = ir;
