@@ -15,13 +15,14 @@
 
 #include "phylo_math.h"
 
-#define PG_TILE 256                    // sites per workgroup of pg_nodes
 #define PG_PART 36                     // per-(node, tile) partial sums: Pl_bar[16], Pr_bar[16], pi_bar[4]
 #define PG_NODEG 22                    // per-node results: bl_bar, br_bar, Q_bar[16], pi_bar[4]
-#define PG_PCHUNK 8                    // parents staged in LDS at a time
+#define PG_PCHUNK 8                    // parents staged in LDS at a time; more parents than this = a heavy node
+#define PG_HCHUNK 32                   // parents per chunk of a heavy node
+#define PG_NT 256                      // sites per workgroup of pg_nodes (4 steps of 64 sites)
 
 struct pg_args {
-    int N, S, K, R, T, jc;
+    int N, S, K, R, T, jc;             // T tiles of PG_NT sites per node
     const double* leaves;              // [N][S][4]
     const double* pool;                // [R][K][S][4]
     double* adj;                       // [R][K][S][4]: d logZ / d node
@@ -35,6 +36,9 @@ struct pg_args {
     const int32_t* roots;              // [R+1][K][N]: plane r+1 = root table after rank event r
     const int32_t *ad_off, *ad_idx;    // [R][K+1], [R][K]: adopters of particle k at rank event r, ascending
     const int32_t *par_off, *par_idx;  // [R K + 1], [<= 2 R K]: parents of internal node x, (node * 2 + side), ascending
+    const int32_t* heavy_first;        // [R K]: first chunk (within its rank event's chunk range) of a heavy node, else -1
+    const int32_t *chunk_beg, *chunk_cnt;   // per chunk: first entry of par_idx, number of entries (<= PG_HCHUNK)
+    double* cpart;                     // [chunks of one rank event][S][4]
     double *om, *G;                    // [R][K]
     double* C;                         // [R][K][N]: coefficient of sum_s log(pi . X) of every root slot after rank event r
     double* part;                      // [R][K][T][PG_PART]
@@ -128,26 +132,31 @@ __global__ __launch_bounds__(256) void pg_omega(pg_args a) {
 }
 
 // ---- g2: G_r[k] = d logZ / d ll_r[k] = omega_r[k] - sum of omega_{r+1} over the particles that adopt k -----
-__global__ __launch_bounds__(256) void pg_G(pg_args a) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= a.R * a.K) return;
+// one wave per (r, k): a surviving particle can have ~K adopters
+__global__ __launch_bounds__(64) void pg_G(pg_args a) {
+    const int t = blockIdx.x, lane = threadIdx.x;
     const int r = t / a.K, k = t - r * a.K;
-    double g = a.om[t];
+    double sub = 0.0;
     if (r + 1 < a.R) {
         const int32_t* off = a.ad_off + (size_t)(r + 1) * (a.K + 1);
         const int32_t* idx = a.ad_idx + (size_t)(r + 1) * a.K;
-        double sub = 0.0;
-        for (int j = off[k]; j < off[k + 1]; ++j) sub = sub + a.om[(size_t)(r + 1) * a.K + idx[j]];
-        g = g - sub;
+        const int beg = off[k], end = off[k + 1];
+        if (end > beg) {
+            for (int j = beg + lane; j < end; j += 64) sub = sub + a.om[(size_t)(r + 1) * a.K + idx[j]];
+            sub = pg_wave_sum(sub);
+        }
     }
-    a.G[t] = g;
+    if (lane == 0) a.G[t] = a.om[t] - sub;
 }
 
-// ---- g3: root-slot coefficients, one rank event per launch (newest first); one wave per particle ----------
+// ---- g3: root-slot coefficients, one rank event per launch (newest first) ---------------------------------
 // C_r[k][slot] = G_r[k] + sum over adopters k' of C_{r+1}[k'][position of that slot in k''s new table]
-__global__ __launch_bounds__(64) void pg_coeff(pg_args a, int r) {
-    const int k = blockIdx.x, lane = threadIdx.x;
+// grid (K, slot groups); 4 waves per workgroup, one slot each.
+__global__ __launch_bounds__(256) void pg_coeff(pg_args a, int r) {
+    const int k = blockIdx.x, lane = threadIdx.x & 63;
+    const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int n1 = a.N - r - 1;
+    if (slot >= n1) return;
     const double g = a.G[(size_t)r * a.K + k];
     double* Ck = a.C + ((size_t)r * a.K + k) * a.N;
     int off = 0, cnt = 0;
@@ -156,23 +165,18 @@ __global__ __launch_bounds__(64) void pg_coeff(pg_args a, int r) {
         off = o[k];
         cnt = o[k + 1] - off;
     }
-    if (cnt == 0) {
-        for (int s = lane; s < n1; s += 64) Ck[s] = g;
-        return;
-    }
-    const int32_t* idx = a.ad_idx + (size_t)(r + 1) * a.K + off;
-    const size_t base = (size_t)(r + 1) * a.K;
-#pragma unroll 1
-    for (int slot = 0; slot < n1; ++slot) {
-        double v = 0.0;
+    double v = 0.0;
+    if (cnt > 0) {
+        const int32_t* idx = a.ad_idx + (size_t)(r + 1) * a.K + off;
+        const size_t base = (size_t)(r + 1) * a.K;
         for (int j = lane; j < cnt; j += 64) {
             const size_t row = (base + idx[j]) * a.N;
             const int p = a.pos[row + slot];
             if (p >= 0) v = v + a.C[row + p];
         }
         v = pg_wave_sum(v);
-        if (lane == 0) Ck[slot] = g + v;
     }
+    if (lane == 0) Ck[slot] = g + v;
 }
 
 // ---- g4: per-leaf sums for d/d pi of the leaf terms -----------------------------------------------------
@@ -211,98 +215,148 @@ __global__ __launch_bounds__(256) void pg_leafterm(pg_args a) {
 }
 
 // ---- g5: node adjoints of one rank event (newest first) ---------------------------------------------------
-// grid (tiles, K); thread per site.  Xbar = alpha pi / (pi . X) + sum over parents (Xbar_parent o (sib P_sib)) P_me^T;
-// then the contributions of this node's own merge to Pl_bar, Pr_bar and of its likelihood term to pi_bar.
-__global__ __launch_bounds__(PG_TILE) void pg_nodes(pg_args a, int r) {
+// Xbar = alpha pi / (pi . X) + sum over parents (Xbar_parent o (sib P_sib)) P_me^T.
+// Quad form: lane 4 q + j owns state j of site q, so every load and store is 8 B per lane, 512 B contiguous per
+// wave; the other three states of the site come from DPP quad broadcasts, and lane j accumulates column j of
+// Pl_bar / Pr_bar (9 running sums per lane instead of 36).
+// After the first resamplings only a handful of lineages survive, so a few nodes have ~K parents and the rest
+// none: a node with more than PG_PCHUNK parents has its parent list cut into chunks of PG_HCHUNK that
+// pg_parent_chunks sums in parallel; pg_nodes then adds the chunk sums in order.  A light node gathers inline.
+template <int I>
+__device__ __forceinline__ double pg_quad(double v) {       // the value held by lane I of my quad
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, I * 0x55, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, I * 0x55, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void pg_stage_parents(const pg_args& a, int c0, int nc, double (*shP)[32], int* shE, int* shSib) {
+    const int e = threadIdx.x >> 5, q = threadIdx.x & 31;
+    if (e < nc) {
+        const int enc = a.par_idx[c0 + e];
+        const int pn = enc >> 1, side = enc & 1;
+        shP[e][q] = a.Pmat[(size_t)pn * 32 + q];
+        if (q == 0) { shE[e] = enc; shSib[e] = a.child[(size_t)pn * 2 + (1 - side)]; }
+    }
+}
+
+// xb (state j of one site) += contributions of the nc staged parents; soff = s * 4 + j
+__device__ __forceinline__ double pg_parent_quad(const pg_args& a, size_t soff, int j, int nc, const double (*shP)[32],
+                                                 const int* shE, const int* shSib, double xb) {
+    const size_t row = (size_t)a.S * 4;
+    for (int e = 0; e < nc; ++e) {
+        const int enc = shE[e];
+        const int pn = enc >> 1, side = enc & 1;
+        const double xp = a.adj[(size_t)pn * row + soff];
+        const double sb = pg_row(a, shSib[e])[soff];
+        const double* Psib = shP[e] + (1 - side) * 16;
+        const double* Pme = shP[e] + side * 16;
+        const double b0 = pg_quad<0>(sb), b1 = pg_quad<1>(sb), b2 = pg_quad<2>(sb), b3 = pg_quad<3>(sb);
+        const double w = ((b0 * Psib[j] + b1 * Psib[4 + j]) + b2 * Psib[8 + j]) + b3 * Psib[12 + j];
+        const double t = xp * w;
+        const double t0 = pg_quad<0>(t), t1 = pg_quad<1>(t), t2 = pg_quad<2>(t), t3 = pg_quad<3>(t);
+        xb = xb + (((t0 * Pme[j * 4] + t1 * Pme[j * 4 + 1]) + t2 * Pme[j * 4 + 2]) + t3 * Pme[j * 4 + 3]);
+    }
+    return xb;
+}
+
+// grid (groups of 64 sites, chunks of this rank event): cpart[chunk][s] = sum of the chunk's parent contributions
+__global__ __launch_bounds__(256) void pg_parent_chunks(pg_args a, int chunk0) {
     __shared__ double shP[PG_PCHUNK][32];
     __shared__ int shE[PG_PCHUNK];
     __shared__ int shSib[PG_PCHUNK];
-    __shared__ double shR[4][PG_PART];
-    const int k = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const int s = tile * PG_TILE + tid;
+    const int ci = blockIdx.y;
+    const int c0 = a.chunk_beg[chunk0 + ci], cnt = a.chunk_cnt[chunk0 + ci];
+    const int s = blockIdx.x * 64 + (threadIdx.x >> 2), j = threadIdx.x & 3;
     const bool live = s < a.S;
+    const size_t soff = (size_t)s * 4 + j;
+    double xb = 0.0;
+    for (int st = 0; st < cnt; st += PG_PCHUNK) {
+        const int nc = cnt - st < PG_PCHUNK ? cnt - st : PG_PCHUNK;
+        __syncthreads();
+        pg_stage_parents(a, c0 + st, nc, shP, shE, shSib);
+        __syncthreads();
+        if (live) xb = pg_parent_quad(a, soff, j, nc, shP, shE, shSib, xb);
+    }
+    if (live) a.cpart[(size_t)ci * a.S * 4 + soff] = xb;
+}
+
+// grid (tiles of PG_NT sites, K)
+__global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
+    __shared__ double shP[PG_PCHUNK][32];
+    __shared__ int shE[PG_PCHUNK];
+    __shared__ int shSib[PG_PCHUNK];
+    __shared__ double shOwn[32];
+    __shared__ double shR[4][9][4];
+    const int k = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int j = tid & 3, q = tid >> 2;
     const size_t node = (size_t)r * a.K + k;
     const size_t row = (size_t)a.S * 4;
     const double alpha = a.C[node * a.N + (a.N - r - 2)];
     const double p0 = a.pi[0], p1 = a.pi[1], p2 = a.pi[2], p3 = a.pi[3];
-    double xb[4] = {0.0, 0.0, 0.0, 0.0}, dpi[4] = {0.0, 0.0, 0.0, 0.0};
-    if (live) {
-        const double* x = a.pool + node * row + (size_t)s * 4;
-        const double x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+    const double pj = a.pi[j];
+    const int pbeg = a.par_off[node], pend = a.par_off[node + 1];
+    const int hv = a.heavy_first[node];
+    const int np = pend - pbeg;
+    const int nch = hv >= 0 ? (np + PG_HCHUNK - 1) / PG_HCHUNK : 0;
+    if (tid < 32) shOwn[tid] = a.Pmat[node * 32 + tid];
+    if (hv < 0 && np > 0) pg_stage_parents(a, pbeg, np, shP, shE, shSib);
+    __syncthreads();
+    const double* Lrow = pg_row(a, a.child[node * 2]);
+    const double* Rrow = pg_row(a, a.child[node * 2 + 1]);
+    const double* xrow = a.pool + node * row;
+    double* orow = a.adj + node * row;
+    const double* Pl = shOwn;
+    const double* Pr = shOwn + 16;
+    double acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = 0.0;
+    const int s_end = (tile + 1) * PG_NT < a.S ? (tile + 1) * PG_NT : a.S;
+#pragma unroll 1
+    for (int s = tile * PG_NT + q; s < s_end; s += 64) {
+        const size_t soff = (size_t)s * 4 + j;
+        const double x = xrow[soff];
+        const double Lj = Lrow[soff], Rj = Rrow[soff];
+        const double x0 = pg_quad<0>(x), x1 = pg_quad<1>(x), x2 = pg_quad<2>(x), x3 = pg_quad<3>(x);
         const double lik = ((p0 * x0 + p1 * x1) + p2 * x2) + p3 * x3;
         const double inv = alpha / lik;
-        xb[0] = p0 * inv; xb[1] = p1 * inv; xb[2] = p2 * inv; xb[3] = p3 * inv;
-        dpi[0] = x0 * inv; dpi[1] = x1 * inv; dpi[2] = x2 * inv; dpi[3] = x3 * inv;
-    }
-    const int pbeg = a.par_off[node], pend = a.par_off[node + 1];
-    for (int c0 = pbeg; c0 < pend; c0 += PG_PCHUNK) {
-        const int nc = (pend - c0) < PG_PCHUNK ? (pend - c0) : PG_PCHUNK;
-        __syncthreads();
-        {
-            const int e = tid >> 5, q = tid & 31;
-            if (e < nc) {
-                const int enc = a.par_idx[c0 + e];
-                const int pn = enc >> 1, side = enc & 1;
-                shP[e][q] = a.Pmat[(size_t)pn * 32 + q];
-                if (q == 0) { shE[e] = enc; shSib[e] = a.child[(size_t)pn * 2 + (1 - side)]; }
+        double xb = pj * inv;
+        acc[8] = acc[8] + x * inv;
+        if (hv >= 0) {
+            const double* cp = a.cpart + (size_t)hv * row + soff;
+            int c = 0;
+            for (; c + 4 <= nch; c += 4) {
+                const double q0 = cp[(size_t)c * row], q1 = cp[(size_t)(c + 1) * row], q2 = cp[(size_t)(c + 2) * row],
+                             q3 = cp[(size_t)(c + 3) * row];
+                xb = (((xb + q0) + q1) + q2) + q3;
             }
+            for (; c < nch; ++c) xb = xb + cp[(size_t)c * row];
+        } else if (np > 0) {
+            xb = pg_parent_quad(a, soff, j, np, shP, shE, shSib, xb);
         }
-        __syncthreads();
-        if (live) {
-            for (int e = 0; e < nc; ++e) {
-                const int enc = shE[e];
-                const int pn = enc >> 1, side = enc & 1;
-                const double* xp = a.adj + (size_t)pn * row + (size_t)s * 4;
-                const double* sb = pg_row(a, shSib[e]) + (size_t)s * 4;
-                const double* Psib = shP[e] + (1 - side) * 16;
-                const double* Pme = shP[e] + side * 16;
-                const double b0 = sb[0], b1 = sb[1], b2 = sb[2], b3 = sb[3];
-                double t[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double w = ((b0 * Psib[j] + b1 * Psib[4 + j]) + b2 * Psib[8 + j]) + b3 * Psib[12 + j];
-                    t[j] = xp[j] * w;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    xb[i] = xb[i] + (((t[0] * Pme[i * 4] + t[1] * Pme[i * 4 + 1]) + t[2] * Pme[i * 4 + 2]) + t[3] * Pme[i * 4 + 3]);
-            }
-        }
-    }
-    double acc[PG_PART];
-#pragma unroll
-    for (int q = 0; q < PG_PART; ++q) acc[q] = 0.0;
-    if (live) {
-        double* o = a.adj + node * row + (size_t)s * 4;
-        o[0] = xb[0]; o[1] = xb[1]; o[2] = xb[2]; o[3] = xb[3];
-        const int cl = a.child[node * 2], cr = a.child[node * 2 + 1];
-        const double* Lr = pg_row(a, cl) + (size_t)s * 4;
-        const double* Rr = pg_row(a, cr) + (size_t)s * 4;
-        const double* Pl = a.Pmat + node * 32;
-        const double* Pr = Pl + 16;
-        const double L[4] = {Lr[0], Lr[1], Lr[2], Lr[3]}, Rv[4] = {Rr[0], Rr[1], Rr[2], Rr[3]};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double u = ((L[0] * Pl[j] + L[1] * Pl[4 + j]) + L[2] * Pl[8 + j]) + L[3] * Pl[12 + j];
-            const double v = ((Rv[0] * Pr[j] + Rv[1] * Pr[4 + j]) + Rv[2] * Pr[8 + j]) + Rv[3] * Pr[12 + j];
-            const double tl = xb[j] * v, tr = xb[j] * u;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i * 4 + j] = L[i] * tl;
-                acc[16 + i * 4 + j] = Rv[i] * tr;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[32 + q] = dpi[q];
+        orow[soff] = xb;
+        const double L0 = pg_quad<0>(Lj), L1 = pg_quad<1>(Lj), L2 = pg_quad<2>(Lj), L3 = pg_quad<3>(Lj);
+        const double R0 = pg_quad<0>(Rj), R1 = pg_quad<1>(Rj), R2 = pg_quad<2>(Rj), R3 = pg_quad<3>(Rj);
+        const double u = ((L0 * Pl[j] + L1 * Pl[4 + j]) + L2 * Pl[8 + j]) + L3 * Pl[12 + j];
+        const double v = ((R0 * Pr[j] + R1 * Pr[4 + j]) + R2 * Pr[8 + j]) + R3 * Pr[12 + j];
+        const double tl = xb * v, tr = xb * u;
+        acc[0] = acc[0] + L0 * tl; acc[1] = acc[1] + L1 * tl; acc[2] = acc[2] + L2 * tl; acc[3] = acc[3] + L3 * tl;
+        acc[4] = acc[4] + R0 * tr; acc[5] = acc[5] + R1 * tr; acc[6] = acc[6] + R2 * tr; acc[7] = acc[7] + R3 * tr;
     }
 #pragma unroll
-    for (int q = 0; q < PG_PART; ++q) {
-        const double v = pg_wave_sum(acc[q]);
-        if ((tid & 63) == 0) shR[tid >> 6][q] = v;
+    for (int i = 0; i < 9; ++i) {                           // over the 16 quads of the wave, state j stays in lane j
+        double v = acc[i];
+        v = v + __shfl_xor(v, 4, 64);
+        v = v + __shfl_xor(v, 8, 64);
+        v = v + __shfl_xor(v, 16, 64);
+        v = v + __shfl_xor(v, 32, 64);
+        if ((tid & 63) < 4) shR[tid >> 6][i][j] = v;
     }
     __syncthreads();
-    if (tid < PG_PART)
-        a.part[(node * a.T + tile) * PG_PART + tid] = ((shR[0][tid] + shR[1][tid]) + shR[2][tid]) + shR[3][tid];
+    if (tid < PG_PART) {                                    // part[i * 4 + j] = Pl_bar[i][j], 16 + .. = Pr_bar, 32 + j = pi_bar[j]
+        const int i = tid < 32 ? (tid >> 2) : 8, jj = tid & 3;
+        a.part[(node * a.T + tile) * PG_PART + tid] = ((shR[0][i][jj] + shR[1][i][jj]) + shR[2][i][jj]) + shR[3][i][jj];
+    }
 }
 
 // ---- g6: per node: tiles -> Pl_bar, Pr_bar -> branch adjoints and the Q adjoint ----------------------------

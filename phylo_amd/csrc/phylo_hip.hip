@@ -76,6 +76,7 @@ struct phylo_ctx {
     double *d_adj = nullptr, *d_om = nullptr, *d_G = nullptr, *d_C = nullptr, *d_part = nullptr, *d_nodeg = nullptr;
     double *d_leafpi = nullptr, *d_leafterm = nullptr, *d_terms = nullptr, *d_gout = nullptr;
     int32_t *d_ad_off = nullptr, *d_ad_idx = nullptr, *d_par_off = nullptr, *d_par_idx = nullptr;
+    int32_t *d_heavy = nullptr, *d_chunk_beg = nullptr, *d_chunk_cnt = nullptr;   // [R K], [<= 2 R K / PG_PCHUNK + 1] x2
     bool graph_ready = false, last_graph = false;
     hipEvent_t evb0 = nullptr, evb1 = nullptr;
     phylo_stats stats{};
@@ -162,13 +163,15 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_rootll_ad = c->d_chosen = c->d_tw_b = c->d_tw_P = c->d_pot = nullptr;
     c->tw_capacity = 0;
     void* gr[] = {c->d_hroots, c->d_hcnt, c->d_pos, c->d_hrootll, c->d_adj, c->d_om, c->d_G, c->d_C, c->d_part, c->d_nodeg,
-                  c->d_leafpi, c->d_leafterm, c->d_terms, c->d_gout, c->d_ad_off, c->d_ad_idx, c->d_par_off, c->d_par_idx};
+                  c->d_leafpi, c->d_leafterm, c->d_terms, c->d_gout, c->d_ad_off, c->d_ad_idx, c->d_par_off, c->d_par_idx,
+                  c->d_heavy, c->d_chunk_beg, c->d_chunk_cnt};
     for (void* p : gr)
         if (p) (void)hipFree(p);
     c->d_hroots = c->d_hcnt = c->d_pos = nullptr;
     c->d_hrootll = c->d_adj = c->d_om = c->d_G = c->d_C = c->d_part = c->d_nodeg = nullptr;
     c->d_leafpi = c->d_leafterm = c->d_terms = c->d_gout = nullptr;
     c->d_ad_off = c->d_ad_idx = c->d_par_off = c->d_par_idx = nullptr;
+    c->d_heavy = c->d_chunk_beg = c->d_chunk_cnt = nullptr;
     c->graph_ready = false;
     c->last_graph = false;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
@@ -238,7 +241,7 @@ int ensure_sweep_state(phylo_ctx* c) {
 int ensure_graph_state(phylo_ctx* c) {
     if (c->graph_ready) return PHYLO_OK;
     const size_t R = (size_t)c->N - 1, K = c->K, N = c->N, S = c->S;
-    const size_t T = (S + PG_TILE - 1) / PG_TILE;
+    const size_t T = (S + PG_NT - 1) / PG_NT;
     CHK(dalloc(c, &c->d_hroots, (R + 1) * K * N));
     CHK(dalloc(c, &c->d_hcnt, (R + 1) * K * N));
     CHK(dalloc(c, &c->d_hrootll, (R + 1) * K * N));
@@ -257,6 +260,9 @@ int ensure_graph_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_ad_idx, R * K));
     CHK(dalloc(c, &c->d_par_off, R * K + 1));
     CHK(dalloc(c, &c->d_par_idx, 2 * R * K));
+    CHK(dalloc(c, &c->d_heavy, R * K));
+    CHK(dalloc(c, &c->d_chunk_beg, 2 * R * K / 4 + 1));
+    CHK(dalloc(c, &c->d_chunk_cnt, 2 * R * K / 4 + 1));
     if (!c->evb0) {
         HIPCHK(c, hipEventCreate(&c->evb0));
         HIPCHK(c, hipEventCreate(&c->evb1));
@@ -859,7 +865,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     if (!c->swept || !c->last_graph)
         return fail(c, PHYLO_ESTATE, "phylo_sweep_backward needs a preceding sweep with PHYLO_KEEP_GRAPH");
     const int N = c->N, K = c->K, S = c->S, R = N - 1;
-    const int T = (S + PG_TILE - 1) / PG_TILE;
+    const int T = (S + PG_NT - 1) / PG_NT;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // integer bookkeeping of the reverse pass: who adopted whom, and which nodes have which parents
     std::vector<int64_t> anc((size_t)(R > 1 ? R - 1 : 0) * K);
@@ -886,12 +892,38 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         for (size_t e = 0; e < 2 * nn; ++e)                // e = node * 2 + side, ascending
             if (child[e] >= N) par_idx[cur[child[e] - N]++] = (int32_t)e;
     }
+    // heavy nodes (more than PG_PCHUNK parents): parent list cut into chunks, numbered within the node's rank event
+    std::vector<int32_t> heavy(nn, -1), chunk_beg, chunk_cnt, rank_chunk0((size_t)R + 1, 0);
+    size_t max_chunks = 0;
+    for (int r = 0; r < R; ++r) {
+        rank_chunk0[r] = (int32_t)chunk_beg.size();
+        for (int k = 0; k < K; ++k) {
+            const size_t x = (size_t)r * K + k;
+            const int np = par_off[x + 1] - par_off[x];
+            if (np <= PG_PCHUNK) continue;
+            heavy[x] = (int32_t)(chunk_beg.size() - rank_chunk0[r]);
+            for (int b = par_off[x]; b < par_off[x + 1]; b += PG_HCHUNK) {
+                chunk_beg.push_back(b);
+                chunk_cnt.push_back(par_off[x + 1] - b < PG_HCHUNK ? par_off[x + 1] - b : PG_HCHUNK);
+            }
+        }
+        if (chunk_beg.size() - rank_chunk0[r] > max_chunks) max_chunks = chunk_beg.size() - rank_chunk0[r];
+    }
+    rank_chunk0[R] = (int32_t)chunk_beg.size();
+    void* cpart = nullptr;
+    CHK(scratch_get(c, 5, max_chunks * (size_t)S * 4 * 8, &cpart));
+    HIPCHK(c, hipMemcpyAsync(c->d_heavy, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (!chunk_beg.empty()) {
+        HIPCHK(c, hipMemcpyAsync(c->d_chunk_beg, chunk_beg.data(), chunk_beg.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_chunk_cnt, chunk_cnt.data(), chunk_cnt.size() * 4, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_ad_off, ad_off.data(), ad_off.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_ad_idx, ad_idx.data(), ad_idx.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_par_off, par_off.data(), par_off.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_par_idx, par_idx.data(), par_idx.size() * 4, hipMemcpyHostToDevice, c->stream));
     pg_args g{};
     g.N = N; g.S = S; g.K = K; g.R = R; g.T = T; g.jc = c->jc;
+    g.heavy_first = c->d_heavy; g.chunk_beg = c->d_chunk_beg; g.chunk_cnt = c->d_chunk_cnt; g.cpart = (double*)cpart;
     g.leaves = c->d_leaves; g.pool = c->d_pool; g.adj = c->d_adj; g.Pmat = c->d_Pmat;
     g.bl = c->d_bl; g.br = c->d_br; g.logw = c->d_logw; g.lse = c->d_lse;
     g.pi = c->d_pi; g.Q = c->d_Q; g.lam_l = c->d_lam_l; g.lam_r = c->d_lam_r;
@@ -903,10 +935,10 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     const int nrk = cdiv((long)R * K, 256);
     hipLaunchKernelGGL(pg_omega, dim3(nrk), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_omega"));
-    hipLaunchKernelGGL(pg_G, dim3(nrk), dim3(256), 0, c->stream, g);
+    hipLaunchKernelGGL(pg_G, dim3(R * K), dim3(64), 0, c->stream, g);
     CHK(launch_check(c, "pg_G"));
     for (int r = R - 1; r >= 0; --r) {
-        hipLaunchKernelGGL(pg_coeff, dim3(K), dim3(64), 0, c->stream, g, r);
+        hipLaunchKernelGGL(pg_coeff, dim3(K, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r);
         CHK(launch_check(c, "pg_coeff"));
     }
     hipLaunchKernelGGL(pg_leafpi, dim3(N), dim3(256), 0, c->stream, g);
@@ -914,7 +946,12 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_leafterm"));
     for (int r = R - 1; r >= 0; --r) {
-        hipLaunchKernelGGL(pg_nodes, dim3(T, K), dim3(PG_TILE), 0, c->stream, g, r);
+        const int nch = rank_chunk0[r + 1] - rank_chunk0[r];
+        if (nch > 0) {
+            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 64), nch), dim3(256), 0, c->stream, g, (int)rank_chunk0[r]);
+            CHK(launch_check(c, "pg_parent_chunks"));
+        }
+        hipLaunchKernelGGL(pg_nodes, dim3(T, K), dim3(256), 0, c->stream, g, r);
         CHK(launch_check(c, "pg_nodes"));
     }
     hipLaunchKernelGGL(pg_node_finish, dim3(cdiv((long)R * K, 64)), dim3(64), 0, c->stream, g);

@@ -1,0 +1,127 @@
+"""The VI training step of VCSMC.train (vcsmc.py:488-491, 532-536): one minibatch sweep, its gradient, one
+optimiser update of the reference's variables.
+
+The reference builds `optimizer.minimize(self.cost)` over four TensorFlow variables and lets autodiff walk
+the sweep.  Here the sweep and its reverse pass run on the device (phylo_sweep with PHYLO_KEEP_GRAPH, then
+phylo_sweep_backward), which returns d logZ / d(lam_l, lam_r, pi, Q); this module owns what is left:
+  * the variables and their parameterisation (vcsmc.py:119-148): log-rates, y_q, y_station;
+  * the chain rules from the raw quantities to those variables (42 numbers, host NumPy);
+  * tf.train.GradientDescentOptimizer / tf.train.AdamOptimizer update rules (TF 1.15 defaults);
+  * the minibatch loop over site slices, including its skipped last slice (vcsmc.py:533, quirk Q9).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _ffi, model
+
+
+class Variables:
+    """tf.trainable_variables() of the reference graph: 'left_branches_param', 'right_branches_param' (the
+    exponents), 'Qmatrix' (y_q) and 'Stationary_probs' (y_station); the last two are constants under --jcmodel."""
+
+    def __init__(self, N, branch_prior, jcmodel, A=4):
+        self.jc = bool(jcmodel)
+        self.a_l = np.zeros(N - 1) + branch_prior               # vcsmc.py:119
+        self.a_r = np.zeros(N - 1) + branch_prior               # vcsmc.py:120
+        self.y_q = model.init_y_q(A)                            # vcsmc.py:122
+        self.y_station = np.zeros(A) + 1 / A                    # vcsmc.py:124
+
+    def names(self):
+        return ('a_l', 'a_r') if self.jc else ('a_l', 'a_r', 'y_q', 'y_station')
+
+    def evaluate(self):
+        """(Q, pi[1,A], lam_l, lam_r) as the graph evaluates them."""
+        Q = model.jc_Q(self.y_q.shape[0]) if self.jc else model.get_Q(self.y_q)
+        return Q, model.get_stationary_probs(self.y_station), np.exp(self.a_l), np.exp(self.a_r)
+
+
+def chain_rules(v, Q, pi_1xA, lam_l, lam_r, raw):
+    """d logZ / d variables from d logZ / d(lam, pi, Q).
+    rates: lam = exp(a).  pi = softmax(y_station) (vcsmc.py:133-136).  Off-diagonal Q_ij = exp(y_ij) / sum_{j' != i}
+    exp(y_ij'), Q_ii = -sum_j Q_ij (vcsmc.py:138-148); diagonal entries of y_q receive no gradient (set_diag)."""
+    g = {'a_l': raw['d_lam_l'] * lam_l, 'a_r': raw['d_lam_r'] * lam_r}
+    if not v.jc:
+        pi = pi_1xA[0]
+        g['y_station'] = pi * (raw['d_pi'] - np.dot(pi, raw['d_pi']))
+        q = np.array(Q, dtype=np.float64)
+        np.fill_diagonal(q, 0.0)
+        dq = raw['d_Q'] - np.diag(raw['d_Q'])[:, None]
+        np.fill_diagonal(dq, 0.0)
+        g['y_q'] = q * (dq - np.sum(q * dq, axis=1, keepdims=True))
+    return g
+
+
+class GradientDescent:
+    """tf.train.GradientDescentOptimizer(lr).minimize(cost): var <- var - lr d cost/d var, cost = -logZ."""
+
+    def __init__(self, learning_rate):
+        self.lr = float(learning_rate)
+
+    def __str__(self):
+        return 'GradientDescentOptimizer(learning_rate=%g)' % self.lr
+
+    def apply(self, v, grads_logZ):
+        for name in v.names():
+            setattr(v, name, getattr(v, name) + self.lr * grads_logZ[name])
+
+
+class Adam:
+    """tf.train.AdamOptimizer (TF 1.15 defaults beta1 .9, beta2 .999, epsilon 1e-8):
+    lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t);  var <- var - lr_t m / (sqrt(v) + epsilon)."""
+
+    def __init__(self, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.lr, self.b1, self.b2, self.eps = float(learning_rate), beta1, beta2, epsilon
+        self.t = 0
+        self.m, self.v = {}, {}
+
+    def __str__(self):
+        return 'AdamOptimizer(learning_rate=%g)' % self.lr
+
+    def apply(self, v, grads_logZ):
+        self.t += 1
+        lr_t = self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        for name in v.names():
+            g = -grads_logZ[name]                                # gradient of the cost
+            m = self.m.get(name, 0.0) * self.b1 + (1.0 - self.b1) * g
+            s = self.v.get(name, 0.0) * self.b2 + (1.0 - self.b2) * g * g
+            self.m[name], self.v[name] = m, s
+            setattr(v, name, getattr(v, name) - lr_t * m / (np.sqrt(s) + self.eps))
+
+
+def make_optimizer(name, learning_rate):
+    """runner.py:30-33: 'Adam' selects Adam, anything else plain gradient descent (vcsmc.py:488-491)."""
+    return Adam(learning_rate) if name == 'Adam' else GradientDescent(learning_rate)
+
+
+class Trainer:
+    """One device context sized for a minibatch of sites; `step` = sweep + reverse pass + update."""
+
+    def __init__(self, genome_NxSxA, K, variables, optimizer, batch_sites, device=0, flags=_ffi.FLAGS_DEFAULT):
+        self.genome = np.asarray(genome_NxSxA, dtype=np.float64)
+        self.v, self.opt = variables, optimizer
+        self.flags = (flags | _ffi.KEEP_GRAPH) & ~_ffi.TWISTING
+        N = self.genome.shape[0]
+        self.ctx = _ffi.Context(K, N, int(batch_sites), device=device)
+        self.last = None
+
+    def close(self):
+        self.ctx.close()
+
+    def gradients(self, sites, seed):
+        """Sweep over genome[:, sites] and its gradient w.r.t. the variables.  Returns (logZ, grads, raw)."""
+        Q, pi, lam_l, lam_r = self.v.evaluate()
+        self.ctx.set_leaves(self.genome[:, sites, :])
+        self.ctx.set_model(Q, pi, lam_l, lam_r, jc69_closed_form=self.v.jc)
+        self.ctx.sweep_async(int(seed), self.flags)
+        out = self.ctx.sweep_fetch(arrays=False)
+        raw = self.ctx.sweep_backward()
+        raw['forward_ms'] = out['stats']['sweep_ms']
+        return out['logZ'], chain_rules(self.v, Q, pi, lam_l, lam_r, raw), raw
+
+    def step(self, sites, seed):
+        """_, cost = sess.run([self.optimizer, self.cost], feed_dict={self.core: data_batch})  (vcsmc.py:534)."""
+        logZ, grads, raw = self.gradients(sites, seed)
+        self.opt.apply(self.v, grads)
+        self.last = {'logZ': logZ, 'grads': grads, 'raw': raw}
+        return -logZ

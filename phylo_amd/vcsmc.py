@@ -8,8 +8,9 @@ Differences that are deliberate:
   * randomness is the counter-based contract of DESIGN.md (`seed` attribute; the reference sets no seed);
   * jump chains are rebuilt on the host from integer merge records, with the correct per-particle gather
     (the reference's vcsmc.py:306-307 gathers without the row offset, fixed in vncsmc.py);
-  * train() evaluates log Z-hat per epoch; the optimiser step (vcsmc.py:488-491, 534) is not part of this
-    build, so model parameters stay at their initial values.
+  * train() takes the reference's optimiser steps (vcsmc.py:488-491, 532-536) with the gradient of the device's
+    reverse pass (phylo_amd/train.py) instead of TensorFlow autodiff; with args.nested the reverse pass of the
+    twisted proposal is not built and train() only evaluates.
 """
 from __future__ import annotations
 
@@ -19,6 +20,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import _ffi, model, rng
+from . import train as train_mod
 
 
 def ncr(n, r):
@@ -76,19 +78,20 @@ class VCSMC:
         self.S = len(self.genome_NxSxA[0])
         self.A = len(self.genome_NxSxA[0, 0])
         self.seed = int(getattr(self.args, 'seed', 0) or 0)
-        self.left_branches_param = model.branch_rates(self.N, self.args.branch_prior)    # vcsmc.py:119
-        self.right_branches_param = model.branch_rates(self.N, self.args.branch_prior)   # vcsmc.py:120
-        if not self.args.jcmodel:
-            self.y_q = model.init_y_q(self.A)                                            # vcsmc.py:122
-            self.Qmatrix = self.get_Q()
-            self.y_station = np.zeros(self.A) + 1 / self.A
-        else:
-            self.Qmatrix = model.jc_Q(self.A)                                            # vcsmc.py:126-129
-            self.y_station = np.zeros(self.A) + 1 / self.A
-        self.stationary_probs = self.get_stationary_probs()
+        # the trainable variables (vcsmc.py:119-130) and what the graph derives from them
+        self.variables = train_mod.Variables(self.N, self.args.branch_prior, self.args.jcmodel, self.A)
+        self._sync_from_variables()
         self._device = device
         self._ctx = None
         self._sweeps = 0
+
+    def _sync_from_variables(self):
+        v = self.variables
+        self.left_branches_param = np.exp(v.a_l)                                         # vcsmc.py:119
+        self.right_branches_param = np.exp(v.a_r)                                        # vcsmc.py:120
+        self.y_q, self.y_station = v.y_q, v.y_station
+        self.Qmatrix = model.jc_Q(self.A) if v.jc else self.get_Q()                      # vcsmc.py:122-129
+        self.stationary_probs = self.get_stationary_probs()
 
     # ---- device context -----------------------------------------------------------------------------
     def _context(self):
@@ -267,7 +270,7 @@ class VCSMC:
             rp.write('Initial evaluation of ELBO : ' + str(initial) + '\n')
             for key, v in vars(self.args).items():
                 rp.write(str(key) + ' : ' + str(v) + '\n')
-            rp.write('optimizer step: not part of this build (parameters stay at their initial values)')
+            rp.write(str(getattr(self, 'optimizer', '')))
         elbos = np.asarray(history['cost'])
         best = int(np.argmax(elbos)) if len(elbos) else 0
         resultDict = {'cost': elbos, 'nParticles': self.K, 'nTaxa': self.N, 'lr': self.lr,
@@ -284,14 +287,24 @@ class VCSMC:
         return resultDict
 
     def train(self, epochs=100, batch_size=128, learning_rate=0.001, memory_optimization='on', save_dir='auto'):
-        """vcsmc.py:466-645 without the optimiser step: one full-S evaluation sweep per epoch (the sweep the
-        reference reports, vcsmc.py:538-551), same printed lines, and the reference's result artefacts
-        (results/<dataset>/<nested>/<K>/<timestamp>/{run_parameters.txt,results.p}; save_dir=None to skip).
-        Returns the per-epoch ELBOs."""
+        """vcsmc.py:466-645: per epoch, one optimiser step per site minibatch (all slices but the last,
+        vcsmc.py:533), then the full-S evaluation sweep the reference reports (vcsmc.py:538-551); same printed
+        lines and result artefacts (results/<dataset>/<nested>/<K>/<timestamp>/{run_parameters.txt,results.p};
+        save_dir=None to skip; no plots).  Returns the per-epoch ELBOs."""
         self.lr = learning_rate
+        data_view = np.broadcast_to(self.genome_NxSxA, (1,) + self.genome_NxSxA.shape)
+        slices = self.batch_slices(data_view, batch_size)
         print('================= Dataset shape: KxNxSxA =================')
         print((self.K, self.N, self.S, self.A))
         print('==========================================================')
+        self.optimizer = train_mod.make_optimizer(getattr(self.args, 'optimizer', ''), self.lr)   # vcsmc.py:488-491
+        nested = bool(getattr(self.args, 'nested', False))
+        trainer = None
+        if nested:
+            print('nested/twisted proposal: the reverse pass is not built; parameters stay at their initial values')
+        elif len(slices) > 1:
+            trainer = train_mod.Trainer(self.genome_NxSxA, self.K, self.variables, self.optimizer, len(slices[0]),
+                                        device=self._device)
         initial = self.sample_phylogenies()
         print('===================\nInitial evaluation of ELBO:', round(initial, 3))
         print('Initial jump chain:')
@@ -301,25 +314,36 @@ class VCSMC:
         elbos = []
         hist = {k: [] for k in ('cost', 'log_weights', 'Qmatrices', 'left_branches', 'right_branches', 'log_lik', 'll_tilde',
                                 'log_lik_R', 'jump_chain_evolution', 'newick')}
-        for i in range(epochs):
-            bt = datetime.now()
-            elbo = self.sample_phylogenies()
-            best_k = int(np.argmax(self.log_likelihood_R))
-            for key, val in (('cost', elbo), ('log_weights', self.log_weights), ('Qmatrices', self.Qmatrix),
-                             ('left_branches', self.left_branches), ('right_branches', self.right_branches),
-                             ('log_lik', self.log_likelihood), ('ll_tilde', self.log_likelihood_tilde),
-                             ('log_lik_R', self.log_likelihood_R), ('jump_chain_evolution', self.jump_chains),
-                             ('newick', self.newick(best_k))):
-                hist[key].append(val)
-            print('Epoch', i + 1)
-            print('ELBO\n', round(elbo, 3))
-            print('Stationary probabilities\n', self.stationary_probs)
-            print('Q-matrix\n', self.Qmatrix)
-            print('LB param:\n', self.left_branches_param)
-            print('RB param:\n', self.right_branches_param)
-            elbos.append(elbo)
-            at = datetime.now()
-            print('Time spent\n', at - bt, '\n-----------------------------------------')
+        self.minibatch_costs = []
+        try:
+            for i in range(epochs):
+                bt = datetime.now()
+                if trainer is not None:
+                    for j in range(len(slices) - 1):                       # vcsmc.py:533 (the last slice is never used)
+                        seed = self.seed + self._sweeps
+                        self._sweeps += 1
+                        self.minibatch_costs.append(trainer.step(slices[j], seed))
+                    self._sync_from_variables()
+                elbo = self.sample_phylogenies()
+                best_k = int(np.argmax(self.log_likelihood_R))
+                for key, val in (('cost', elbo), ('log_weights', self.log_weights), ('Qmatrices', self.Qmatrix),
+                                 ('left_branches', self.left_branches), ('right_branches', self.right_branches),
+                                 ('log_lik', self.log_likelihood), ('ll_tilde', self.log_likelihood_tilde),
+                                 ('log_lik_R', self.log_likelihood_R), ('jump_chain_evolution', self.jump_chains),
+                                 ('newick', self.newick(best_k))):
+                    hist[key].append(val)
+                print('Epoch', i + 1)
+                print('ELBO\n', round(elbo, 3))
+                print('Stationary probabilities\n', self.stationary_probs)
+                print('Q-matrix\n', self.Qmatrix)
+                print('LB param:\n', self.left_branches_param)
+                print('RB param:\n', self.right_branches_param)
+                elbos.append(elbo)
+                at = datetime.now()
+                print('Time spent\n', at - bt, '\n-----------------------------------------')
+        finally:
+            if trainer is not None:
+                trainer.close()
         print("Done training.")
         self.elbos = np.asarray(elbos)
         if save_dir is not None:
