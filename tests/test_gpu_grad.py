@@ -200,3 +200,20 @@ def test_vcsmc_train_takes_optimizer_steps(tmp_path):
     assert 'AdamOptimizer' in (tmp_path / 'run_parameters.txt').read_text()
     assert np.mean(elbos[-2:]) > np.mean(elbos[:2]), elbos
     v.close()
+
+
+@pytest.mark.parametrize("N,S,K", [(2, 5, 4), (3, 1, 1), (3, 7, 2), (4, 65, 3)])
+def test_gradient_edge_shapes(N, S, K):
+    """Two taxa (one rank event, no resampling), one particle, one site, a ragged 64-site group."""
+    rng = np.random.default_rng(100 + N * 10 + K)
+    genome = _codes_genome(rng, N, S)
+    Q, pi, ll, lr = _model(rng, N)
+    _check(genome, Q, pi, ll, lr, K=K, seed=6)
+
+
+def test_gradient_many_taxa():
+    """27 taxa (DS1 sites): root tables longer than one slot group of pg_coeff, deep adoption chains."""
+    genome = load_dataset('hohna_data_1')['genome'][:, :130]
+    rng = np.random.default_rng(31)
+    Q, pi, ll, lr = _model(rng, genome.shape[0], spread=0.2, lam=2.3)
+    _check(genome, Q, pi, ll, lr, K=40, seed=12)
