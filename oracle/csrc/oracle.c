@@ -351,6 +351,28 @@ int ora_sweep(const double* genome /*[N][S][4]*/, const double* Q, const double*
     return 0;
 }
 
+/* Leaf codes of the reference's encoding (runner.py:83-96): 0..3 one-hot state, 4 all-ones.  Returns 1 when every
+ * leaf row is one of them.  For such alignments the look-ahead potential of a leaf-leaf pair is priced by state
+ * pair: sum_s log f(c_l[s], c_r[s]) = sum over the 25 code pairs of count * log f (contract v3);
+ * term of code pair c goes to canonical column c. */
+static int leaf_codes(const double* genome, size_t rows, uint8_t* codes) {
+    for (size_t i = 0; i < rows; ++i) {
+        const double* x = genome + i * 4;
+        int ones = 0, zeros = 0, last = 0;
+        for (int j = 0; j < 4; ++j) {
+            if (x[j] == 1.0) { ++ones; last = j; }
+            else if (ora_bits(x[j]) == 0) ++zeros;
+        }
+        if (ones == 1 && zeros == 3) codes[i] = (uint8_t)last;
+        else if (ones == 4) codes[i] = 4;
+        else return 0;
+    }
+    return 1;
+}
+static void code_row(int c, double* v) {
+    for (int j = 0; j < 4; ++j) v[j] = (c == 4 || c == j) ? 1.0 : 0.0;
+}
+
 /* ---- T: the twisted / nested proposal, vncsmc.py:295-416 + 432-499, same dataflow as ora_sweep -------- */
 /* potentials_out (may be NULL): [(N-1)][K][Jmax] raw (un-normalised) look-ahead potentials, Jmax = C(N,2)*M,
  * rows padded with zeros (test surface for the potentials kernel). */
@@ -372,11 +394,21 @@ int ora_sweep_twisted(const double* genome, const double* Q, const double* pi, c
     double* ll_tilde = (double*)malloc((size_t)K * sizeof(double));
     uint64_t* cdf = (uint64_t*)malloc((size_t)K * sizeof(uint64_t));
     double* lse = (double*)malloc((size_t)R * sizeof(double));
-    if (!coreA || !coreB || !recA || !recB || !lw || !ll || !bls || !brs || !ll_tilde || !cdf || !lse) return -1;
+    int32_t* lidA = (int32_t*)malloc((size_t)K * N * sizeof(int32_t));     /* leaf id of every root slot, -1 = internal */
+    int32_t* lidB = (int32_t*)malloc((size_t)K * N * sizeof(int32_t));
+    uint8_t* codes = (uint8_t*)malloc((size_t)N * S);
+    uint32_t* hist = (uint32_t*)calloc((size_t)N * N * 25, sizeof(uint32_t));
+    if (!coreA || !coreB || !recA || !recB || !lw || !ll || !bls || !brs || !ll_tilde || !cdf || !lse || !lidA || !lidB ||
+        !codes || !hist) return -1;
+    const int coded = leaf_codes(genome, (size_t)N * S, codes);
+    if (coded)
+        for (int a = 0; a < N; ++a)
+            for (int b = 0; b < N; ++b)
+                for (int s = 0; s < S; ++s) ++hist[((size_t)a * N + b) * 25 + codes[(size_t)a * S + s] * 5 + codes[(size_t)b * S + s]];
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < K; ++k) {
         memcpy(coreA + (size_t)k * part, genome, part * sizeof(double));
-        for (int i = 0; i < N; ++i) recA[(size_t)k * N + i] = 1;
+        for (int i = 0; i < N; ++i) { recA[(size_t)k * N + i] = 1; lidA[(size_t)k * N + i] = i; }
     }
     const double ll_tilde0 = ora_log(1.0 / (double)K);
     for (int k = 0; k < K; ++k) ll_tilde[k] = ll_tilde0;
@@ -393,11 +425,13 @@ int ora_sweep_twisted(const double* genome, const double* Q, const double* pi, c
                 int a = cdf_search(cdf, K, ora_mulhi64(Rr, cdf[K - 1]));
                 memcpy(coreB + (size_t)k * part, coreA + (size_t)a * part, (size_t)n * node * sizeof(double));
                 memcpy(recB + (size_t)k * N, recA + (size_t)a * N, (size_t)n * sizeof(int32_t));
+                memcpy(lidB + (size_t)k * N, lidA + (size_t)a * N, (size_t)n * sizeof(int32_t));
                 ll_tilde[k] = ll[(size_t)(r - 1) * K + a];
                 if (ancestors) ancestors[(size_t)(r - 1) * K + k] = a;
             }
             double* tc = coreA; coreA = coreB; coreB = tc;
             int32_t* tr_ = recA; recA = recB; recB = tr_;
+            tr_ = lidA; lidA = lidB; lidB = tr_;
         }
         const double laml = lam_l[r], lamr = lam_r[r];
         const double loglaml = ora_log(laml), loglamr = ora_log(lamr);
@@ -407,6 +441,8 @@ int ora_sweep_twisted(const double* genome, const double* Q, const double* pi, c
             double* dst = coreB + (size_t)k * part;
             const int32_t* rs = recA + (size_t)k * N;
             int32_t* rd = recB + (size_t)k * N;
+            const int32_t* ls = lidA + (size_t)k * N;
+            int32_t* ld = lidB + (size_t)k * N;
             double* pot = (double*)malloc((size_t)J * sizeof(double));
             double* wv = (double*)malloc((size_t)J * sizeof(double));
             double* tmp = (double*)malloc(node * sizeof(double));
@@ -427,8 +463,25 @@ int ora_sweep_twisted(const double* genome, const double* Q, const double* pi, c
                         if (jc) { ora_jc69(tl, Pl); ora_jc69(tr, Pr); } else { ora_expm4(Q, tl, Pl); ora_expm4(Q, tr, Pr); }
                         const double* L = src + (size_t)r1 * node;
                         const double* Rr = src + (size_t)r2 * node;
-                        for (int s = 0; s < S; ++s) merge_site(L + (size_t)s * 4, Rr + (size_t)s * 4, Pl, Pr, tmp + (size_t)s * 4);
-                        double jp = row_loglik(pi, tmp, S) + (-log_double_factorial_count(rs[r1] + rs[r2]));
+                        double merged_ll;
+                        if (coded && ls[r1] >= 0 && ls[r2] >= 0) {          /* leaf-leaf pair: 25 code pairs */
+                            const uint32_t* h = hist + ((size_t)ls[r1] * N + ls[r2]) * 25;
+                            ora_canon cs;
+                            ora_canon_init(&cs);
+                            for (int cp = 0; cp < 25; ++cp) {
+                                if (!h[cp]) continue;
+                                double Lv[4], Rv[4], o[4];
+                                code_row(cp / 5, Lv);
+                                code_row(cp % 5, Rv);
+                                merge_site(Lv, Rv, Pl, Pr, o);
+                                ora_canon_add(&cs, cp, (double)h[cp] * ora_log(site_lik(pi, o)));
+                            }
+                            merged_ll = ora_canon_total(&cs);
+                        } else {
+                            for (int s = 0; s < S; ++s) merge_site(L + (size_t)s * 4, Rr + (size_t)s * 4, Pl, Pr, tmp + (size_t)s * 4);
+                            merged_ll = row_loglik(pi, tmp, S);
+                        }
+                        double jp = merged_ll + (-log_double_factorial_count(rs[r1] + rs[r2]));
                         jp = jp - (rowll[r1] + (-log_double_factorial_count(rs[r1])));
                         jp = jp - (rowll[r2] + (-log_double_factorial_count(rs[r2])));
                         pot[j] = jp;
@@ -479,8 +532,10 @@ int ora_sweep_twisted(const double* genome, const double* Q, const double* pi, c
                 if (i == il || i == ir) continue;
                 memcpy(dst + (size_t)nrem * node, src + (size_t)i * node, node * sizeof(double));
                 rd[nrem] = rs[i];
+                ld[nrem] = ls[i];
                 ++nrem;
             }
+            ld[nrem] = -1;
             double* nw = dst + (size_t)nrem * node;
             for (int s = 0; s < S; ++s) merge_site(src + (size_t)il * node + (size_t)s * 4, src + (size_t)ir * node + (size_t)s * 4, Pl, Pr, nw + (size_t)s * 4);
             rd[nrem] = rs[il] + rs[ir];
@@ -504,9 +559,11 @@ int ora_sweep_twisted(const double* genome, const double* Q, const double* pi, c
             lw[(size_t)r * K + k] = (((llr - ll_tilde[k]) - paren) + ora_log((double)vminus)) - logq;   /* vncsmc.py:489-491 */
             free(pot); free(wv); free(tmp);
         }
-        { double* tc = coreA; coreA = coreB; coreB = tc; int32_t* tr_ = recA; recA = recB; recB = tr_; }
+        { double* tc = coreA; coreA = coreB; coreB = tc; int32_t* tr_ = recA; recA = recB; recB = tr_;
+          tr_ = lidA; lidA = lidB; lidB = tr_; }
     }
     lse[R - 1] = weights_prepare(lw + (size_t)(R - 1) * K, K, NULL);
+    free(lidA); free(lidB); free(codes); free(hist);
     double z = 0.0;
     for (int r = 0; r < R; ++r) z = z + lse[r];
     if (logZ) *logZ = z;

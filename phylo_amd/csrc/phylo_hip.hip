@@ -45,6 +45,8 @@ struct phylo_ctx {
     double* d_leaves = nullptr;          // [N][S][4]
     uint8_t* d_leaf_codes = nullptr;     // [N][S]; in use only when every leaf row is one-hot or all-ones
     bool leaves_coded = false;
+    uint32_t* d_pair_hist = nullptr;     // [N][N][32] code-pair site counts of coded leaves (built on the first twisted sweep)
+    bool hist_ready = false, codes_valid = false;
     // sweep state
     double* d_pool = nullptr;            // [(N-1)][Kloc][S][4]
     double* d_nodell = nullptr;          // [N + (N-1)*K]
@@ -370,7 +372,7 @@ int phylo_set_leaves(phylo_ctx* c, const double* genome) {
     {
         const size_t rows = (size_t)c->N * c->S;
         std::vector<uint8_t> codes(rows);
-        bool ok = !getenv("PHYLO_NO_LEAF_CODES");
+        bool ok = true;
         for (size_t i = 0; i < rows && ok; ++i) {
             const double* x = genome + i * 4;
             int ones = 0, zeros = 0, last = 0;
@@ -382,7 +384,9 @@ int phylo_set_leaves(phylo_ctx* c, const double* genome) {
             else if (ones == 4) codes[i] = 4;
             else ok = false;
         }
-        c->leaves_coded = ok;
+        c->codes_valid = ok;                                  // a property of the data (the twisting contract uses it)
+        c->leaves_coded = ok && !getenv("PHYLO_NO_LEAF_CODES");   // the access-path optimisation can be switched off
+        c->hist_ready = false;
         if (ok) HIPCHK(c, hipMemcpy(c->d_leaf_codes, codes.data(), rows, hipMemcpyHostToDevice));
     }
     c->have_leaves = true;
@@ -604,6 +608,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         if (M < 1 || M > PK_TWIST_MAX_M) return fail(c, PHYLO_EINVAL, "twisting needs 1 <= M <= %d (got %d)", PK_TWIST_MAX_M, M);
         const size_t Jmax = (size_t)(N * (N - 1) / 2) * M;
         if (Jmax > PK_TWIST_MAX_J) return fail(c, PHYLO_EINVAL, "twisting: C(N,2)*M = %zu exceeds %d", Jmax, PK_TWIST_MAX_J);
+        if ((N - 1) * M > PK_TWIST_MAX_ROWS) return fail(c, PHYLO_EINVAL, "twisting: (N-1)*M = %d exceeds %d", (N - 1) * M, PK_TWIST_MAX_ROWS);
         if (!c->d_roots_ad) {
             CHK(dalloc(c, &c->d_roots_ad, (size_t)K * N));
             CHK(dalloc(c, &c->d_cnt_ad, (size_t)K * N));
@@ -619,6 +624,12 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
             CHK(dalloc(c, &c->d_pot, (size_t)Kl * Jmax));
             c->tw_capacity = (size_t)Kl * Jmax;
         }
+    }
+    if (twist && c->codes_valid && !c->hist_ready) {
+        if (!c->d_pair_hist) CHK(dalloc(c, &c->d_pair_hist, (size_t)N * N * 32));
+        hipLaunchKernelGGL(pk_pair_hist, dim3(N, N), dim3(256), 0, c->stream, (const uint8_t*)c->d_leaf_codes, N, S, c->d_pair_hist);
+        CHK(launch_check(c, "pk_pair_hist"));
+        c->hist_ready = true;
     }
     const bool timek = (flags & PHYLO_TIME_KERNELS) != 0;
     if (timek && (int)c->kev.size() < 2 * R) {
@@ -696,11 +707,17 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
             ta.roots_ad = c->d_roots_ad; ta.cnt_ad = c->d_cnt_ad; ta.rootll_ad = c->d_rootll_ad;
             ta.tw_b = c->d_tw_b; ta.tw_P = c->d_tw_P; ta.pot = c->d_pot; ta.chosen = c->d_chosen;
             ta.Pmat_r = c->d_Pmat + (size_t)r * Kl * 32;
+            ta.pair_hist = c->codes_valid ? c->d_pair_hist : nullptr;
             ta.bl_r = c->d_bl + (size_t)r * Kl; ta.br_r = c->d_br + (size_t)r * Kl;
             hipLaunchKernelGGL(pk_twist_adopt, dim3(K), dim3(64), 0, c->stream, ta);
             CHK(launch_check(c, "pk_twist_adopt"));
             hipLaunchKernelGGL(pk_twist_draws, dim3(cdiv(2L * Kl * ta.J, 64)), dim3(64), 0, c->stream, ta, (const double*)c->d_Q, c->jc);
             CHK(launch_check(c, "pk_twist_draws"));
+            if (ta.pair_hist) {                            // coded leaf-leaf pairs: 25 code pairs per row instead of S sites
+                hipLaunchKernelGGL(pk_twist_potentials_ll, dim3((ta.J + 7) / 8, Kl), dim3(256), 0, c->stream, ta);
+                CHK(launch_check(c, "pk_twist_potentials_ll"));
+                ++launches;
+            }
             hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((size_t)Kl * (N - r - 1))), dim3(PK_COLS), 0, c->stream, ta);
             CHK(launch_check(c, "pk_twist_potentials"));
             hipLaunchKernelGGL(pk_twist_choose, dim3(Kl), dim3(64), (size_t)ta.J * 8, c->stream, ta);

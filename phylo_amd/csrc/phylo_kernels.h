@@ -971,7 +971,21 @@ struct pk_twist_args {
     double* chosen;                  // [K] chosen j per global particle (as double: travels with the RCCL all-gather)
     double* Pmat_r;                  // [Kloc][32] matrices of the chosen sub-sample (input of pk_rank_merge)
     double* bl_r; double* br_r;      // [Kloc] rows r of the branch-length history
+    const uint32_t* pair_hist;       // [N][N][32] or NULL: sites per code pair (c_l * 5 + c_r) of two coded leaves
 };
+
+// sites per code pair of every ordered pair of coded leaves: grid (N, N).  Integer LDS atomics (exact).
+__global__ __launch_bounds__(256) void pk_pair_hist(const uint8_t* __restrict__ codes, int N, int S, uint32_t* __restrict__ hist) {
+    __shared__ unsigned int h[32];
+    const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (tid < 32) h[tid] = 0u;
+    __syncthreads();
+    const uint8_t* ca = codes + (size_t)a * S;
+    const uint8_t* cb = codes + (size_t)b * S;
+    for (int s = tid; s < S; s += 256) atomicAdd(&h[ca[s] * 5 + cb[s]], 1u);
+    __syncthreads();
+    if (tid < 32) hist[((size_t)a * N + b) * 32 + tid] = h[tid];
+}
 
 __global__ __launch_bounds__(64) void pk_twist_adopt(const pk_twist_args ta) {
     const pk_rank_args& a = ta.a;
@@ -1079,10 +1093,78 @@ __device__ __forceinline__ double pk_uniform(double v) {
     return __hiloint2double(hi, lo);
 }
 #define PK_TWIST_LDS_ROWS 8              // (pair, sub-sample) rows staged and reduced per pass
+#define PK_TWIST_MAX_ROWS 512            // (N-1) M of one workgroup; C(N,2) M <= PK_TWIST_MAX_J and M <= 16 keep it below 360
+
+// (leaf row of `code` . P)[j], bit-identical to pk_build_leaf_table
+__device__ __forceinline__ double pk_leaf_entry(const double* __restrict__ P, int code, int j) {
+    if (code < 4) return P[code * 4 + j];
+    return pm_fma(1.0, P[12 + j], pm_fma(1.0, P[8 + j], pm_fma(1.0, P[4 + j], 1.0 * P[j])));
+}
+
+// Potentials of the pairs of two CODED LEAVES: the merged row takes 25 distinct values, so
+// sum_s log f(c_l[s], c_r[s]) = sum over code pairs c of count_c log f_c (contract v3): the
+// term of code pair c sits in canonical column c, every other column is 0, same tree.  32 lanes per
+// (particle, pair, sub-sample) row; rows of other pairs leave at once (pk_twist_potentials computes those).
+__global__ __launch_bounds__(256) void pk_twist_potentials_ll(const pk_twist_args ta) {
+    __shared__ __attribute__((aligned(16))) double Psh[8][32];
+    __shared__ __attribute__((aligned(16))) double tab[8][2][5][4];
+    const pk_rank_args& a = ta.a;
+    const int n = a.n, M = ta.M, J = ta.J;
+    const int q = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const int k = blockIdx.y, j = blockIdx.x * 8 + q, kg = a.k0 + k;   // grid (ceil(J / 8), Kloc)
+    const int32_t* ro = ta.roots_ad + (size_t)kg * a.N;
+    bool active = j < J;
+    int r1 = 0, r2 = 1, idl = 0, idr = 0;
+    if (active) {
+        int rem = j / M;
+        while (rem >= n - 1 - r1) { rem -= n - 1 - r1; ++r1; }
+        r2 = r1 + 1 + rem;
+        idl = ro[r1]; idr = ro[r2];
+        active = idl < a.N && idr < a.N;
+    }
+    unsigned int cnt = 0;
+    if (active) {
+        Psh[q][c] = ta.tw_P[((size_t)k * J + j) * 32 + c];
+        if (c < 25) cnt = ta.pair_hist[((size_t)idl * a.N + idr) * 32 + c];
+    }
+    __syncthreads();
+    if (active) {
+        pk_build_leaf_table(&Psh[q][0], tab[q][0], c);          // 20 entries per side
+        if (c < 20) pk_build_leaf_table(&Psh[q][16], tab[q][1], c);
+    }
+    __syncthreads();
+    if (!active) return;
+    double term = 0.0;
+    if (cnt) {
+        const int cl = c / 5, cr = c - cl * 5;
+        const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+        double o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = tab[q][0][cl][u] * tab[q][1][cr][u];
+        term = (double)cnt * pm_log(pk_site_lik(pi, o));
+    }
+    double v = 0.0 + term;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) v = v + __shfl_xor(v, off, 64);
+    if (c == 0) {
+        v = v + 0.0;                                           // column 32 of the 64-column tree
+        const double tot = ((v + 0.0) + 0.0) + 0.0;            // column groups 1..3
+        const int32_t* co = ta.cnt_ad + (size_t)kg * a.N;
+        const double* rl = ta.rootll_ad + (size_t)kg * a.N;
+        const int c1 = co[r1], c2 = co[r2], c12 = c1 + c2;
+        double jp = tot + (-a.ldf[c12 < a.ldf_n ? c12 : a.ldf_n]);
+        jp = jp - (rl[r1] + (-a.ldf[c1 < a.ldf_n ? c1 : a.ldf_n]));
+        jp = jp - (rl[r2] + (-a.ldf[c2 < a.ldf_n ? c2 : a.ldf_n]));
+        ta.pot[(size_t)k * J + j] = jp;
+    }
+}
+
 __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist_args ta) {
     __shared__ double cols[PK_TWIST_LDS_ROWS][PK_COLS];
     __shared__ __attribute__((aligned(16))) double Psh[PK_TWIST_LDS_ROWS][32];
     __shared__ __attribute__((aligned(16))) double tab[PK_TWIST_LDS_ROWS][2][5][4];
+    __shared__ short rowlist[PK_TWIST_MAX_ROWS];
+    __shared__ int nlist;
     const pk_rank_args& a = ta.a;
     const int n = a.n, M = ta.M, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int k = blockIdx.x / (n - 1), r1 = blockIdx.x - k * (n - 1), kg = a.k0 + k;
@@ -1095,13 +1177,31 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     // pair index of (r1, r1+1): sum_{i<r1} (n-1-i)
     const int t0 = r1 * (n - 1) - r1 * (r1 - 1) / 2;
-    const int nrows = (n - 1 - r1) * M;                  // rows of this workgroup: (r2 - r1 - 1) * M + m
+    const int nrows_all = (n - 1 - r1) * M;              // rows of this workgroup: (r2 - r1 - 1) * M + m
+    // rows left for this kernel: everything but the coded leaf-leaf pairs (pk_twist_potentials_ll)
+    const bool llL = ta.pair_hist && idl < a.N;
+    if (!llL) {
+        for (int i = tid; i < nrows_all; i += PK_COLS) rowlist[i] = (short)i;
+        if (tid == 0) nlist = nrows_all;
+    } else if (tid < 64) {                               // wave 0 compacts in row order
+        int base = 0;
+        for (int i0 = 0; i0 < nrows_all; i0 += 64) {
+            const int i = i0 + tid;
+            const bool keep = i < nrows_all && ro[r1 + 1 + i / M] >= a.N;
+            const unsigned long long m = __ballot(keep);
+            if (keep) rowlist[base + __popcll(m & ((1ull << tid) - 1ull))] = (short)i;
+            base += __popcll(m);
+        }
+        if (tid == 0) nlist = base;
+    }
+    __syncthreads();
+    const int nrows = nlist;
     const double* Pblock = ta.tw_P + ((size_t)k * ta.J + (size_t)t0 * M) * 32;   // rows are contiguous in j
     for (int base = 0; base < nrows; base += PK_TWIST_LDS_ROWS) {
         const int cnt = nrows - base < PK_TWIST_LDS_ROWS ? nrows - base : PK_TWIST_LDS_ROWS;
         // stage the transition matrices of this pass and the leaf lookup tables built from them: one global
         // round trip per pass instead of one per row
-        for (int i = tid; i < cnt * 32; i += PK_COLS) Psh[i >> 5][i & 31] = Pblock[(size_t)(base + (i >> 5)) * 32 + (i & 31)];
+        for (int i = tid; i < cnt * 32; i += PK_COLS) Psh[i >> 5][i & 31] = Pblock[(size_t)rowlist[base + (i >> 5)] * 32 + (i & 31)];
         __syncthreads();
         for (int i = tid; i < cnt * 40; i += PK_COLS) {
             const int q = i / 40, e = i - q * 40, side = e / 20;
@@ -1109,7 +1209,7 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist
         }
         __syncthreads();
         for (int q = 0; q < cnt; ++q) {
-            const int row = base + q, r2 = r1 + 1 + row / M;
+            const int row = rowlist[base + q], r2 = r1 + 1 + row / M;
             const int idr = ro[r2];
             const double* Rp = pk_node_ptr(a, idr);
             const bool cR = a.leaf_codes && idr < a.N;
@@ -1137,7 +1237,7 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist
             }
             if (lane == 0) {
                 const double tot = ((g[0] + g[1]) + g[2]) + g[3];
-                const int row = base + q, r2 = r1 + 1 + row / M, m = row - (row / M) * M;
+                const int row = rowlist[base + q], r2 = r1 + 1 + row / M, m = row - (row / M) * M;
                 const int c1 = co[r1], c2 = co[r2], c12 = c1 + c2;
                 double jp = tot + (-a.ldf[c12 < a.ldf_n ? c12 : a.ldf_n]);
                 jp = jp - (rl[r1] + (-a.ldf[c1 < a.ldf_n ? c1 : a.ldf_n]));

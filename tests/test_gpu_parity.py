@@ -325,15 +325,21 @@ def test_many_taxa_bookkeeping_paths():
 def test_leaf_code_path_equals_generic_path(primate, monkeypatch):
     """The 1-byte leaf codes are an access-path optimisation only: same bits as reading the rows."""
     Q = O.get_Q(O.init_y_q())
+    tw = _ffi.FLAGS_DEFAULT | _ffi.TWISTING
     a = make_ctx(primate, 96, Q)
     ra = a.sweep(5)
+    ta = a.sweep(5, flags=tw, M=2)
     a.close()
     monkeypatch.setenv("PHYLO_NO_LEAF_CODES", "1")
     b = make_ctx(primate, 96, Q)
     rb = b.sweep(5)
+    tb = b.sweep(5, flags=tw, M=2)
     b.close()
     assert_bit_equal(ra['log_weights'], rb['log_weights'], "coded vs generic leaves")
     np.testing.assert_array_equal(ra['ancestors'], rb['ancestors'])
+    # twisting: leaf-leaf potentials are priced by code pair whenever the DATA is coded, whichever access path runs
+    assert_bit_equal(ta['log_weights'], tb['log_weights'], "twisted, coded vs generic leaves")
+    np.testing.assert_array_equal(ta['merges'], tb['merges'])
 
 
 def test_hohna_ds1_config4_shape():
