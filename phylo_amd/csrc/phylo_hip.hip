@@ -718,7 +718,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
                 CHK(launch_check(c, "pk_twist_potentials_ll"));
                 ++launches;
             }
-            hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((size_t)Kl * (N - r - 1))), dim3(PK_COLS), 0, c->stream, ta);
+            hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((((size_t)Kl * (N - r - 1) + 7) / 8) * 8)), dim3(PK_COLS), 0, c->stream, ta);
             CHK(launch_check(c, "pk_twist_potentials"));
             hipLaunchKernelGGL(pk_twist_choose, dim3(Kl), dim3(64), (size_t)ta.J * 8, c->stream, ta);
             CHK(launch_check(c, "pk_twist_choose"));

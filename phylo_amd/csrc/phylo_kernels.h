@@ -1167,7 +1167,11 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist
     __shared__ int nlist;
     const pk_rank_args& a = ta.a;
     const int n = a.n, M = ta.M, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int k = blockIdx.x / (n - 1), r1 = blockIdx.x - k * (n - 1), kg = a.k0 + k;
+    // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of particles, so that the
+    // n-1 workgroups of a particle (which read the same internal roots) share one L2.  gridDim.x is a multiple of 8.
+    const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (bid >= a.Kloc * (n - 1)) return;
+    const int k = bid / (n - 1), r1 = bid - k * (n - 1), kg = a.k0 + k;
     const int32_t* ro = ta.roots_ad + (size_t)kg * a.N;
     const int32_t* co = ta.cnt_ad + (size_t)kg * a.N;
     const double* rl = ta.rootll_ad + (size_t)kg * a.N;
