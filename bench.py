@@ -109,9 +109,7 @@ def main():
     ndev = _ffi.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
-    n_streams = a.streams if a.streams > 0 else (3 if world == 1 else 1)
-    if world > 1:
-        n_streams = 1                                 # one RCCL communicator per context; keep it simple when sharded
+    n_streams = a.streams if a.streams > 0 else 3
     pool_bytes = 32.0 * (N - 1) * a.n_particles * S   # node pool of one context
     while n_streams > 1 and n_streams * pool_bytes > 200e9:
         n_streams -= 1                                # every sweep in flight owns a pool; stay inside 288 GB of HBM
@@ -125,12 +123,27 @@ def main():
     if world > 1:
         cid = exchange_comm_id(rank, world, _ffi.comm_unique_id if rank == 0 else None)
         ctx.comm_init(rank, world, cid)
+        for c in ctxs[1:]:                            # further sweeps in flight: same communicator, one comm stream
+            c.comm_share(ctx)
 
     sweep_flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if a.twisting else 0)
 
     def run(n, seed0):
-        for s in range(n):
-            ctxs[s % n_streams].sweep_async(seed0 + s, flags=sweep_flags, M=a.M)
+        if world == 1 or n_streams == 1:
+            for s in range(n):
+                ctxs[s % n_streams].sweep_async(seed0 + s, flags=sweep_flags, M=a.M)
+        else:
+            # sharded: the sweeps in flight advance rank event by rank event (A0 B0 C0 A1 B1 C1 ...), so every rank
+            # issues the collectives of the shared communicator in the same order while the other sweeps compute
+            for s0 in range(0, n, n_streams):
+                group = ctxs[:min(n_streams, n - s0)]
+                for i, c in enumerate(group):
+                    c.sweep_begin(seed0 + s0 + i, flags=sweep_flags, M=a.M)
+                for _ in range(N - 1):
+                    for c in group:
+                        c.sweep_step()
+                for c in group:
+                    c.sweep_finish()
         for c in ctxs:
             c.synchronize()
 
@@ -194,7 +207,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds, a.M if a.twisting else 0)
         print(json.dumps(line), flush=True)
-    for c in ctxs:
+    for c in reversed(ctxs):                          # sharers before the owner of the communicator
         c.close()
 
 

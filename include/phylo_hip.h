@@ -137,6 +137,15 @@ int phylo_sweep_fetch(phylo_ctx* ctx, double* log_weights, double* log_lik, doub
                       phylo_stats* perf);
 int phylo_synchronize(phylo_ctx* ctx);
 
+/* The same sweep issued one rank event at a time: begin (draws, tables), N-1 x step, finish (log Z-hat).
+ * phylo_sweep_async is exactly begin + steps + finish.  A caller that keeps several sweeps in flight on sharded
+ * contexts interleaves them rank event by rank event (A0 B0 C0 A1 B1 C1 ...), so that the collectives of the
+ * shared communicator (phylo_comm_share) are issued in one order on every rank while the kernels of the other
+ * sweeps run underneath them. */
+int phylo_sweep_begin(phylo_ctx* ctx, uint64_t seed, uint32_t flags, int M);
+int phylo_sweep_step(phylo_ctx* ctx);
+int phylo_sweep_finish(phylo_ctx* ctx);
+
 /* Partial-likelihood vector of the node created at rank event r by particle slot k in the last sweep,
  * [S,4] (test surface for the merge kernel inside the sweep).  After a lazy sweep the missing nodes are
  * written first; when sharded that step is a collective: every rank must make the call. */
@@ -163,6 +172,10 @@ int phylo_comm_unique_id(char id[PHYLO_COMM_ID_BYTES]);
  * particles [rank*K/world, (rank+1)*K/world) and sweep outputs are this shard's columns. */
 int phylo_comm_init(phylo_ctx* ctx, int rank, int world, const char id[PHYLO_COMM_ID_BYTES]);
 /* barrier + max over ranks of *value (RCCL all-reduce); identity when no comm is set. */
+/* A further context of this process joins `owner`'s communicator (same rank, same world) instead of creating its
+ * own: all collectives of the process then run on one stream of one communicator, in host issue order.  Collective
+ * (peer pools are mapped); every rank makes the call for its contexts in the same order.  `owner` must outlive ctx. */
+int phylo_comm_share(phylo_ctx* ctx, phylo_ctx* owner);
 int phylo_comm_max(phylo_ctx* ctx, double* value);
 int phylo_comm_barrier(phylo_ctx* ctx);
 

@@ -26,9 +26,10 @@ EXPORTS = [
     "phylo_version", "phylo_last_error", "phylo_device_count", "phylo_create", "phylo_destroy",
     "phylo_set_leaves", "phylo_set_model", "phylo_expm_batched", "phylo_cond_likelihood_K",
     "phylo_forest_loglik", "phylo_tree_loglik", "phylo_resample", "phylo_log_zsmc", "phylo_sweep",
-    "phylo_sweep_async", "phylo_sweep_fetch", "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
+    "phylo_sweep_async", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_finish", "phylo_sweep_fetch",
+    "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
     "phylo_math_probe",
-    "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_max", "phylo_comm_barrier",
+    "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_max", "phylo_comm_barrier",
 ]
 
 
@@ -183,6 +184,15 @@ class Context:
     def sweep_async(self, seed, flags=FLAGS_DEFAULT, M=1):
         self._check(self._lib.phylo_sweep_async(self._h, C.c_uint64(seed), C.c_uint32(flags), C.c_int(M)))
 
+    def sweep_begin(self, seed, flags=FLAGS_DEFAULT, M=1):
+        self._check(self._lib.phylo_sweep_begin(self._h, C.c_uint64(seed), C.c_uint32(flags), C.c_int(M)))
+
+    def sweep_step(self):
+        self._check(self._lib.phylo_sweep_step(self._h))
+
+    def sweep_finish(self):
+        self._check(self._lib.phylo_sweep_finish(self._h))
+
     def synchronize(self):
         self._check(self._lib.phylo_synchronize(self._h))
 
@@ -229,6 +239,14 @@ class Context:
         self._check(self._lib.phylo_comm_init(self._h, C.c_int(rank), C.c_int(world), buf))
         self.K_local = self.K // world
         self.k0 = rank * self.K_local
+
+    def comm_share(self, owner):
+        """Join `owner`'s communicator (a further sweep in flight on the same rank); keep `owner` alive."""
+        self._check(self._lib.phylo_comm_share(self._h, owner._h))
+        self._owner = owner
+        world = owner.K // owner.K_local
+        self.K_local = self.K // world
+        self.k0 = (owner.k0 // owner.K_local) * self.K_local
 
     def comm_max(self, value):
         v = C.c_double(float(value))

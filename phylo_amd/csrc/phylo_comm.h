@@ -47,7 +47,15 @@ struct phylo_comm {
     size_t shm_bytes = 0, slot_bytes = 0;
     // peer pools
     std::vector<void*> peer_base;      // opened IPC mappings (nullptr for self)
+    // several contexts of one process on ONE communicator (phylo_comm_share): the sharers point at the owner; every
+    // collective of the process then runs on the owner's dedicated stream, in host issue order, so that all ranks
+    // see one communicator used from one stream in one order however many sweeps are in flight
+    phylo_comm* parent = nullptr;
+    hipStream_t cstream = nullptr;     // owner only, created by the first phylo_comm_share
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
+
+inline phylo_comm& phylo_comm_link(phylo_comm& c) { return c.parent ? *c.parent : c; }
 
 #define PHYLO_SHM_SLOT (4u << 20)      // per-rank slot of the host-mediated transport
 
@@ -97,6 +105,14 @@ inline void phylo_comm_destroy(phylo_comm* c) {
     for (void* p : c->peer_base)
         if (p) (void)hipIpcCloseMemHandle(p);
     c->peer_base.clear();
+    if (c->ev_in) { (void)hipEventDestroy(c->ev_in); c->ev_in = nullptr; }
+    if (c->ev_out) { (void)hipEventDestroy(c->ev_out); c->ev_out = nullptr; }
+    if (c->parent) {                   // a sharer owns nothing else
+        c->parent = nullptr;
+        c->transport = 0; c->world = 1; c->rank = 0;
+        return;
+    }
+    if (c->cstream) { (void)hipStreamDestroy(c->cstream); c->cstream = nullptr; }
     if (c->nccl) { (void)ncclCommDestroy(c->nccl); c->nccl = nullptr; }
     if (c->shm) {
         munmap(c->shm, c->shm_bytes);
@@ -154,16 +170,28 @@ inline int phylo_comm_setup(phylo_comm* c, int rank, int world, const char* id, 
 
 // In-place all-gather of `n_arrays` device arrays of `count` doubles each (count = per-rank elements; array i
 // holds world*count elements, this rank's at offset rank*count).
-inline int phylo_comm_allgather_inplace(phylo_comm& c, double* const* arrays, int n_arrays, size_t count,
+inline int phylo_comm_allgather_inplace(phylo_comm& me, double* const* arrays, int n_arrays, size_t count,
                                         hipStream_t stream, std::string* err) {
-    if (c.transport == 0) return PHYLO_OK;
+    if (me.transport == 0) return PHYLO_OK;
+    phylo_comm& c = phylo_comm_link(me);
     if (c.transport == 1) {
+        hipStream_t cs = stream;
+        if (c.cstream) {               // shared communicator: hop onto its stream and back
+            if (!me.ev_in && (hipEventCreateWithFlags(&me.ev_in, hipEventDisableTiming) != hipSuccess ||
+                              hipEventCreateWithFlags(&me.ev_out, hipEventDisableTiming) != hipSuccess))
+                return phylo_comm_fail(err, "hipEventCreate", "shared communicator");
+            if (hipEventRecord(me.ev_in, stream) != hipSuccess || hipStreamWaitEvent(c.cstream, me.ev_in, 0) != hipSuccess)
+                return phylo_comm_fail(err, "hipStreamWaitEvent", "shared communicator (in)");
+            cs = c.cstream;
+        }
         ncclResult_t r = ncclGroupStart();
         for (int i = 0; i < n_arrays && r == ncclSuccess; ++i)
-            r = ncclAllGather(arrays[i] + (size_t)c.rank * count, arrays[i], count, ncclDouble, c.nccl, stream);
+            r = ncclAllGather(arrays[i] + (size_t)c.rank * count, arrays[i], count, ncclDouble, c.nccl, cs);
         ncclResult_t r2 = ncclGroupEnd();
         if (r != ncclSuccess || r2 != ncclSuccess)
             return phylo_comm_fail(err, "ncclAllGather", ncclGetErrorString(r != ncclSuccess ? r : r2));
+        if (c.cstream && (hipEventRecord(me.ev_out, cs) != hipSuccess || hipStreamWaitEvent(stream, me.ev_out, 0) != hipSuccess))
+            return phylo_comm_fail(err, "hipStreamWaitEvent", "shared communicator (out)");
         return PHYLO_OK;
     }
     const size_t bytes = count * sizeof(double), total = bytes * n_arrays;
@@ -188,7 +216,7 @@ inline int phylo_comm_allgather_inplace(phylo_comm& c, double* const* arrays, in
 
 // all-gather of small host blobs (IPC handles) through a device bounce buffer
 inline int phylo_comm_allgather_host(phylo_comm& c, const void* mine, size_t bytes, void* all, hipStream_t stream,
-                                     std::string* err) {
+                                     std::string* err) {   // c may be a sharer: rank/world are mirrored, the link is resolved below
     if (c.transport == 0) { memcpy(all, mine, bytes); return PHYLO_OK; }
     const size_t count = (bytes + 7) / 8;
     double* d = nullptr;

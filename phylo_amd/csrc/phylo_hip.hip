@@ -27,6 +27,13 @@ struct DevBuf {
 
 }  // namespace
 
+struct sweep_run {                       // a sweep being issued rank event by rank event
+    uint64_t seed = 0;
+    uint32_t flags = 0;
+    int M = 1, launches = 0, next_r = 0;
+    bool twist = false, graph = false, lazy = false, timek = false, fuse_scan = false, active = false;
+};
+
 struct phylo_ctx {
     int device = 0;
     int K = 0, N = 0, S = 0, A = 4;      // K = global particle count
@@ -82,6 +89,7 @@ struct phylo_ctx {
     bool graph_ready = false, last_graph = false;
     hipEvent_t evb0 = nullptr, evb1 = nullptr;
     phylo_stats stats{};
+    sweep_run run;
     int n_merge_events = 0;
     // grow-only scratch for the op-level entry points
     DevBuf scratch[6];
@@ -593,9 +601,9 @@ int phylo_log_zsmc(phylo_ctx* c, const double* logw, int R, int K, double* out) 
     return PHYLO_OK;
 }
 
-int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
+int phylo_sweep_begin(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     CHK(bind(c));
-    (void)M;
+    c->run.active = false;
     if (!c->have_leaves || !c->have_model)
         return fail(c, PHYLO_ESTATE, "phylo_set_leaves and phylo_set_model must be called before a sweep");
     if (!c->state_ready) {
@@ -652,7 +660,7 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     const bool lazy = lazy_ok && (S >= 8192 || getenv("PHYLO_LAZY_NODES"));
     int launches = 0;
     const bool fuse_scan = !twist && !graph && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
-    const size_t lds = pk_book_lds_bytes(N);
+    c->swept = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (lazy) HIPCHK(c, hipMemsetAsync(c->d_mark, 0, (((size_t)R * K + R + 3) & ~(size_t)3) * sizeof(unsigned int), c->stream));
     if (!twist) {
@@ -660,14 +668,33 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
                            c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat);
         CHK(launch_check(c, "pk_sweep_draws"));
     }
-    const size_t plane = (size_t)K * N;
     hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream,
                        graph ? c->d_hroots : c->d_roots[0], graph ? c->d_hcnt : c->d_cnt[0],
                        graph ? c->d_hrootll : c->d_rootll[0], (const double*)c->d_nodell, K, N);
     CHK(launch_check(c, "pk_init_tables"));
     launches += 2;
+    c->run = sweep_run{};
+    c->run.seed = seed; c->run.flags = flags; c->run.M = M;
+    c->run.twist = twist; c->run.graph = graph; c->run.lazy = lazy; c->run.timek = timek; c->run.fuse_scan = fuse_scan;
+    c->run.launches = launches; c->run.next_r = 0; c->run.active = true;
+    return PHYLO_OK;
+}
+
+int phylo_sweep_step(phylo_ctx* c) {
+    CHK(bind(c));
+    if (!c->run.active) return fail(c, PHYLO_ESTATE, "phylo_sweep_step without phylo_sweep_begin");
+    const int N = c->N, K = c->K, Kl = c->Kloc, S = c->S, R = N - 1;
+    if (c->run.next_r >= R) return fail(c, PHYLO_ESTATE, "all %d rank events of this sweep have been issued", R);
+    const uint64_t seed = c->run.seed;
+    const uint32_t flags = c->run.flags;
+    const int M = c->run.M;
+    const bool twist = c->run.twist, graph = c->run.graph, lazy = c->run.lazy, timek = c->run.timek, fuse_scan = c->run.fuse_scan;
+    int launches = 0;
+    const size_t lds = pk_book_lds_bytes(N);
+    const size_t plane = (size_t)K * N;
+    const int r = c->run.next_r;
     const double ll_tilde0 = pm_log(1.0 / (double)K);      // vcsmc.py:422
-    for (int r = 0; r < R; ++r) {
+    {
         const int cur = r & 1, nxt = cur ^ 1;
         pk_rank_args b{};
         b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
@@ -778,11 +805,27 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
             }
         }
     }
+    c->run.launches += launches;
+    ++c->run.next_r;
+    return PHYLO_OK;
+}
+
+int phylo_sweep_finish(phylo_ctx* c) {
+    CHK(bind(c));
+    const int N = c->N, Kl = c->Kloc, S = c->S, R = N - 1;
+    if (!c->run.active || c->run.next_r != R)
+        return fail(c, PHYLO_ESTATE, "phylo_sweep_finish needs phylo_sweep_begin and all %d phylo_sweep_step calls", R);
+    const uint32_t flags = c->run.flags;
+    const int M = c->run.M;
+    const bool twist = c->run.twist, graph = c->run.graph, lazy = c->run.lazy, timek = c->run.timek;
+    int launches = c->run.launches;
+    (void)flags;
     hipLaunchKernelGGL(pk_logz_total, dim3(1), dim3(64), 0, c->stream, (const double*)c->d_lse, R, c->d_lse + R);
     CHK(launch_check(c, "pk_logz_total"));
     ++launches;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->swept = true;
+    c->run.active = false;
     c->last_lazy = lazy;
     c->last_graph = graph;
     c->n_merge_events = timek ? R : 0;
@@ -795,6 +838,12 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         c->stats.alg_bytes += 64.0 * ut;
     }
     return PHYLO_OK;
+}
+
+int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
+    CHK(phylo_sweep_begin(c, seed, flags, M));
+    for (int r = 0; r < c->N - 1; ++r) CHK(phylo_sweep_step(c));
+    return phylo_sweep_finish(c);
 }
 
 int phylo_synchronize(phylo_ctx* c) {
@@ -1033,6 +1082,33 @@ int phylo_comm_init(phylo_ctx* c, int rank, int world, const char id[PHYLO_COMM_
     c->world = world;
     c->Kloc = c->K / world;
     c->k0 = rank * c->Kloc;
+    c->swept = false;
+    c->state_ready = false;
+    CHK(alloc_sweep_state(c));                             // collective: every rank maps every peer's pool here
+    CHK(refresh_leaf_ll(c));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_comm_share(phylo_ctx* c, phylo_ctx* owner) {
+    CHK(bind(c));
+    if (!owner || owner == c) return fail(c, PHYLO_EINVAL, "phylo_comm_share needs another context as the owner");
+    if (owner->comm.parent) return fail(c, PHYLO_EINVAL, "the owner must hold its own communicator (phylo_comm_init)");
+    if (owner->device != c->device) return fail(c, PHYLO_EINVAL, "both contexts must live on the same device");
+    if (c->K % owner->world != 0) return fail(c, PHYLO_EINVAL, "K = %d is not divisible by world = %d", c->K, owner->world);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_sweep_state(c);
+    phylo_comm_destroy(&c->comm);
+    if (owner->comm.transport == 1 && !owner->comm.cstream)
+        HIPCHK(c, hipStreamCreateWithFlags(&owner->comm.cstream, hipStreamNonBlocking));
+    c->comm.parent = &owner->comm;
+    c->comm.rank = owner->comm.rank;
+    c->comm.world = owner->comm.world;
+    c->comm.transport = owner->comm.transport;
+    c->rank = owner->rank;
+    c->world = owner->world;
+    c->Kloc = c->K / c->world;
+    c->k0 = c->rank * c->Kloc;
     c->swept = false;
     c->state_ready = false;
     CHK(alloc_sweep_state(c));                             // collective: every rank maps every peer's pool here

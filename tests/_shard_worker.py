@@ -29,14 +29,44 @@ def main():
     res = None
     twist_M = int(os.environ.get('PHYLO_TEST_TWIST_M', '0'))
     flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if twist_M else 0)
-    for s in range(n_sweeps):                     # back-to-back sweeps reuse the node pool slabs
-        res = ctx.sweep(seed + s, flags=flags, M=max(twist_M, 1))
+    inflight = int(os.environ.get('PHYLO_TEST_INFLIGHT', '1'))
+    others = []
+    if inflight > 1:
+        # several sweeps in flight on this rank: further contexts share ctx's communicator and all of them advance
+        # rank event by rank event (bench.py's sharded loop).  Sweep i of the group uses seed + i; the LAST context's
+        # result (seed + inflight - 1) is reported.
+        for i in range(1, inflight):
+            c2 = _ffi.Context(K, N, S, device=int(os.environ.get('PHYLO_TEST_DEVICE', '0')))
+            c2.set_leaves(g)
+            c2.set_model(Q, pi, lam, lam, jc69_closed_form=jc)
+            c2.comm_share(ctx)
+            others.append(c2)
+        group = [ctx] + others
+        for rep in range(n_sweeps):
+            for i, c in enumerate(group):
+                c.sweep_begin(seed + i, flags=flags, M=max(twist_M, 1))
+            for _ in range(N - 1):
+                for c in group:
+                    c.sweep_step()
+            for c in group:
+                c.sweep_finish()
+        first = ctx.sweep_fetch()
+        res = group[-1].sweep_fetch()
+        res['first_logZ'] = first['logZ']
+        ctx_report = group[-1]
+    else:
+        for s in range(n_sweeps):                     # back-to-back sweeps reuse the node pool slabs
+            res = ctx.sweep(seed + s, flags=flags, M=max(twist_M, 1))
+        ctx_report = ctx
     t = ctx.comm_max(float(rank))
     assert t == world - 1, t
     ctx.comm_barrier()
-    node = ctx.sweep_node(N - 2, ctx.K_local - 1)
+    node = ctx_report.sweep_node(N - 2, ctx.K_local - 1)
     np.savez(out, log_weights=res['log_weights'], log_likelihood=res['log_likelihood'], ancestors=res['ancestors'],
-             merges=res['merges'], left_branches=res['left_branches'], logZ=res['logZ'], node=node, k0=ctx.k0)
+             merges=res['merges'], left_branches=res['left_branches'], logZ=res['logZ'], node=node, k0=ctx_report.k0,
+             first_logZ=res.get('first_logZ', res['logZ']))
+    for c in reversed(others):
+        c.close()
     ctx.close()
 
 
