@@ -1,8 +1,12 @@
 """Sharded restatement of the sweep (TEST INFRASTRUCTURE): the multi-GPU protocol of DESIGN.md in NumPy.
 
-Each rank owns the particles [rank*K/G, (rank+1)*K/G).  Integer state (root tables, leaf counts) is
-REPLICATED and advanced for all K particles on every rank from the shared counter-based draws; float state
-(node partial likelihoods) exists only on the owner.  Per rank event the ranks all-gather three K-vectors
+Each rank owns the particles [rank*K/G, (rank+1)*K/G).  Float state (node partial likelihoods) exists only on
+the owner.  Integer state (root tables, leaf counts), two forms:
+  * local_tables=True (the GPU default when sharded): a rank advances only ITS particles' rows; at a resampling
+    the rows of an adopted ancestor are read from the ancestor's OWNER (`comm.gather_tables`, on the GPU a read
+    of the owner's table slab over the peer mapping);
+  * local_tables=False (PHYLO_REPLICATED_BOOK=1): rows of all K particles are REPLICATED and advanced on every
+    rank from the shared counter-based draws.  Per rank event the ranks all-gather three K-vectors
 (log-weights, log-likelihoods, node log-likelihoods); a child node owned by another rank is fetched from its
 owner when (and only when) it is merged.  `comm` needs all_gather(np.ndarray) -> list of arrays and
 fetch_node(owner, key) (tests wire these to torch.distributed gloo).  The result must equal cpu_ref.sweep.
@@ -14,7 +18,7 @@ import numpy as np
 from . import cpu_ref as O
 
 
-def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, flags=O.QUIRK_Q1_RAW_Q):
+def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, flags=O.QUIRK_Q1_RAW_Q, local_tables=False):
     N, S, A = genome.shape
     Kl = K // world
     k0 = rank * Kl
@@ -45,6 +49,11 @@ def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, f
         n = N - r
         if r > 0:
             idx = O.resample_indices(log_weights[r - 1], seed, r)        # identical on every rank
+            if local_tables:                                            # ancestors' rows come from their owners
+                parts = comm.gather_tables((roots[local], cnt[local], rootll[local]))
+                roots = np.concatenate([p[0] for p in parts])
+                cnt = np.concatenate([p[1] for p in parts])
+                rootll = np.concatenate([p[2] for p in parts])
             roots, cnt, rootll = roots[idx], cnt[idx], rootll[idx]
             ll_tilde = log_lik[r - 1, idx]
             ancestors[r - 1] = idx
@@ -81,6 +90,10 @@ def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, f
         roots = np.concatenate([roots_rem, new_ids[:, None]], axis=1)
         cnt = cnt_new
         rootll = np.concatenate([ll_rem, node_ll_all[:, None]], axis=1)
+        if local_tables:                                                # rows of other ranks' particles are not mine to keep
+            other = np.ones(K, dtype=bool)
+            other[local] = False
+            roots[other], cnt[other], rootll[other] = -1, -1, np.nan
     logZ = O.compute_log_ZSMC(np.concatenate([np.zeros((1, K)), log_weights]))
     return {'log_weights': log_weights, 'log_likelihood': log_lik, 'ancestors': ancestors, 'logZ': logZ,
             'remote_fetches': fetched}

@@ -47,6 +47,7 @@ struct phylo_comm {
     size_t shm_bytes = 0, slot_bytes = 0;
     // peer pools
     std::vector<void*> peer_base;      // opened IPC mappings (nullptr for self)
+    std::vector<void*> peer_extra;     // further mapped buffers of the peers (root tables)
     // several contexts of one process on ONE communicator (phylo_comm_share): the sharers point at the owner; every
     // collective of the process then runs on the owner's dedicated stream, in host issue order, so that all ranks
     // see one communicator used from one stream in one order however many sweeps are in flight
@@ -105,6 +106,9 @@ inline void phylo_comm_destroy(phylo_comm* c) {
     for (void* p : c->peer_base)
         if (p) (void)hipIpcCloseMemHandle(p);
     c->peer_base.clear();
+    for (void* p : c->peer_extra)
+        if (p) (void)hipIpcCloseMemHandle(p);
+    c->peer_extra.clear();
     if (c->ev_in) { (void)hipEventDestroy(c->ev_in); c->ev_in = nullptr; }
     if (c->ev_out) { (void)hipEventDestroy(c->ev_out); c->ev_out = nullptr; }
     if (c->parent) {                   // a sharer owns nothing else
@@ -244,6 +248,9 @@ inline int phylo_comm_map_pools(phylo_comm& c, void* my_pool, std::vector<void*>
                                 std::string* err) {
     for (void* p : c.peer_base)
         if (p) (void)hipIpcCloseMemHandle(p);
+    for (void* p : c.peer_extra)
+        if (p) (void)hipIpcCloseMemHandle(p);
+    c.peer_extra.clear();
     c.peer_base.assign(c.world, nullptr);
     ptrs_out->assign(c.world, nullptr);
     (*ptrs_out)[c.rank] = my_pool;
@@ -260,6 +267,29 @@ inline int phylo_comm_map_pools(phylo_comm& c, void* my_pool, std::vector<void*>
         e = hipIpcOpenMemHandle(&base, all[p], hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) return phylo_comm_fail(err, "hipIpcOpenMemHandle", hipGetErrorString(e));
         c.peer_base[p] = base;
+        (*ptrs_out)[p] = base;
+    }
+    return PHYLO_OK;
+}
+
+// Same exchange for one more buffer per rank (the root-table slab); call after phylo_comm_map_pools.
+inline int phylo_comm_map_extra(phylo_comm& c, void* mine_dev, std::vector<void*>* ptrs_out, hipStream_t stream,
+                                std::string* err) {
+    ptrs_out->assign(c.world, nullptr);
+    (*ptrs_out)[c.rank] = mine_dev;
+    if (c.world == 1) return PHYLO_OK;
+    hipIpcMemHandle_t mine;
+    hipError_t e = hipIpcGetMemHandle(&mine, mine_dev);
+    if (e != hipSuccess) return phylo_comm_fail(err, "hipIpcGetMemHandle", hipGetErrorString(e));
+    std::vector<hipIpcMemHandle_t> all(c.world);
+    int rc = phylo_comm_allgather_host(c, &mine, sizeof(mine), all.data(), stream, err);
+    if (rc != PHYLO_OK) return rc;
+    for (int p = 0; p < c.world; ++p) {
+        if (p == c.rank) continue;
+        void* base = nullptr;
+        e = hipIpcOpenMemHandle(&base, all[p], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return phylo_comm_fail(err, "hipIpcOpenMemHandle", hipGetErrorString(e));
+        c.peer_extra.push_back(base);
         (*ptrs_out)[p] = base;
     }
     return PHYLO_OK;

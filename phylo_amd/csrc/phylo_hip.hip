@@ -31,7 +31,7 @@ struct sweep_run {                       // a sweep being issued rank event by r
     uint64_t seed = 0;
     uint32_t flags = 0;
     int M = 1, launches = 0, next_r = 0;
-    bool twist = false, graph = false, lazy = false, timek = false, fuse_scan = false, active = false;
+    bool twist = false, graph = false, lazy = false, timek = false, fuse_scan = false, active = false, local_book = false;
 };
 
 struct phylo_ctx {
@@ -61,8 +61,12 @@ struct phylo_ctx {
     double *d_logw = nullptr, *d_ll = nullptr;                    // [(N-1)][K] (global columns)
     double* d_aux = nullptr;             // [Kloc][PK_AUX]
     double* d_lse = nullptr;             // [N-1] + total
+    // root tables, two planes each, carved from ONE slab (so that peers map it with one handle):
+    // rootll[0], rootll[1] (double), roots[0], roots[1], cnt[0], cnt[1] (int32), each [K][N]
+    char* d_tables = nullptr;
     int32_t *d_roots[2] = {nullptr, nullptr}, *d_cnt[2] = {nullptr, nullptr};   // [K][N]
     double* d_rootll[2] = {nullptr, nullptr};                                   // [K][N]
+    const char** d_tab_ptrs = nullptr;   // [world] table slab of every rank (peer mappings)
     int32_t* d_child = nullptr;          // [(N-1)][Kloc][2]: children of every node (kept for lazy materialisation)
     unsigned int* d_mark = nullptr;      // [(N-1)][K]: node is in the pool
     double* d_sync = nullptr;  // [world] dummy payload of the barrier collective used by lazy nodes when sharded
@@ -185,8 +189,8 @@ void free_sweep_state(phylo_ctx* c) {
     c->graph_ready = false;
     c->last_graph = false;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
-                    c->d_roots[0], c->d_roots[1], c->d_cnt[0], c->d_cnt[1], c->d_child, c->d_merges, c->d_anc,
-                    c->d_cdf[0], c->d_cdf[1], c->d_counter, c->d_rootll[0], c->d_rootll[1], (void*)c->d_pool_ptrs, c->d_mark, c->d_mat_list, c->d_sync};
+                    c->d_tables, (void*)c->d_tab_ptrs, c->d_child, c->d_merges, c->d_anc,
+                    c->d_cdf[0], c->d_cdf[1], c->d_counter, (void*)c->d_pool_ptrs, c->d_mark, c->d_mat_list, c->d_sync};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_pool = c->d_nodell = c->d_bl = c->d_br = c->d_Pmat = c->d_logw = c->d_ll = c->d_aux = c->d_lse = nullptr;
@@ -195,6 +199,8 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_cdf[0] = c->d_cdf[1] = nullptr;
     c->d_counter = nullptr;
     c->d_rootll[0] = c->d_rootll[1] = nullptr;
+    c->d_tables = nullptr;
+    c->d_tab_ptrs = nullptr;
     c->d_pool_ptrs = nullptr;
     c->d_mark = nullptr;
     c->d_mat_list = nullptr;
@@ -215,10 +221,11 @@ int alloc_sweep_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_ll, R * K));
     CHK(dalloc(c, &c->d_aux, Kl * PK_AUX));
     CHK(dalloc(c, &c->d_lse, R + 1));
+    CHK(dalloc(c, &c->d_tables, 32 * K * N));
     for (int i = 0; i < 2; ++i) {
-        CHK(dalloc(c, &c->d_roots[i], K * N));
-        CHK(dalloc(c, &c->d_cnt[i], K * N));
-        CHK(dalloc(c, &c->d_rootll[i], K * N));
+        c->d_rootll[i] = reinterpret_cast<double*>(c->d_tables) + (size_t)i * K * N;
+        c->d_roots[i] = reinterpret_cast<int32_t*>(c->d_tables + 16 * K * N) + (size_t)i * K * N;
+        c->d_cnt[i] = reinterpret_cast<int32_t*>(c->d_tables + 24 * K * N) + (size_t)i * K * N;
     }
     CHK(dalloc(c, &c->d_child, R * Kl * 2));
     CHK(dalloc(c, &c->d_mark, ((R * K + R + 3) & ~(size_t)3)));      // marks, then the per-rank queue counters
@@ -236,6 +243,10 @@ int alloc_sweep_state(phylo_ctx* c) {
     int rc = phylo_comm_map_pools(c->comm, c->d_pool, &ptrs, c->stream, &c->err);
     if (rc != PHYLO_OK) return rc;
     HIPCHK(c, hipMemcpy((void*)c->d_pool_ptrs, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice));
+    CHK(dalloc(c, &c->d_tab_ptrs, (size_t)c->world));
+    rc = phylo_comm_map_extra(c->comm, c->d_tables, &ptrs, c->stream, &c->err);
+    if (rc != PHYLO_OK) return rc;
+    HIPCHK(c, hipMemcpy((void*)c->d_tab_ptrs, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice));
     c->state_ready = true;
     return PHYLO_OK;
 }
@@ -768,7 +779,18 @@ int phylo_sweep_step(phylo_ctx* c) {
             CHK(launch_check(c, "pk_rank_scan_book"));
             ++launches;
         } else {
-            hipLaunchKernelGGL(pk_rank_book, dim3(K), dim3(64), lds, c->stream, b);
+            // sharded, plain proposal, eager nodes: every rank advances only ITS particles' root tables and reads an
+            // adopted ancestor's row from the owner's slab over the peer mapping (ordered by the all-gather of the
+            // previous rank event, like the node pool) instead of replicating the bookkeeping of all K particles
+            const bool local_book = c->world > 1 && !lazy && !getenv("PHYLO_REPLICATED_BOOK");
+            if (local_book) {
+                b.tab_ptrs = c->d_tab_ptrs;
+                b.tab_off_rootll = (size_t)cur * K * N * 8;
+                b.tab_off_roots = (size_t)16 * K * N + (size_t)cur * K * N * 4;
+                b.tab_off_cnt = (size_t)24 * K * N + (size_t)cur * K * N * 4;
+            }
+            c->run.local_book = local_book;
+            hipLaunchKernelGGL(pk_rank_book, dim3(local_book ? Kl : K), dim3(64), lds, c->stream, b);
             CHK(launch_check(c, "pk_rank_book"));
             ++launches;
         }
@@ -791,10 +813,12 @@ int phylo_sweep_step(phylo_ctx* c) {
             if (c->comm.transport != 0) {
                 double* rows[3] = {c->d_logw + (size_t)r * K, c->d_ll + (size_t)r * K, c->d_nodell + N + (size_t)r * K};
                 CHK(phylo_comm_allgather_inplace(c->comm, rows, 3, (size_t)Kl, c->stream, &c->err));
-                hipLaunchKernelGGL(pk_fix_rootll, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, c->d_rootll[nxt],
-                                   (const double*)(c->d_nodell + N + (size_t)r * K), K, N, N - r, c->k0, Kl);
-                CHK(launch_check(c, "pk_fix_rootll"));
-                ++launches;
+                if (!c->run.local_book) {
+                    hipLaunchKernelGGL(pk_fix_rootll, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, c->d_rootll[nxt],
+                                       (const double*)(c->d_nodell + N + (size_t)r * K), K, N, N - r, c->k0, Kl);
+                    CHK(launch_check(c, "pk_fix_rootll"));
+                    ++launches;
+                }
             }
             if (!fuse_scan || twist || r + 1 == R) {           // otherwise the next rank event's launch scans these weights
                 hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream,

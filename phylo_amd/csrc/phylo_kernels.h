@@ -471,6 +471,10 @@ struct pk_rank_args {
     int32_t* child;                                       // [Kloc][2] (row r of child_all): node ids merged at this rank event
     double* aux;                                          // [Kloc][PK_AUX]: weight terms for the merge epilogue
     int32_t* pos_hist;                                    // [K][N] or NULL (PHYLO_KEEP_GRAPH): adopted slot -> new position, -1 = merged
+    // sharded local bookkeeping: the grid covers this rank's particles only; an ancestor's rows of the previous
+    // plane are read from its OWNER's table slab (peer mapping), byte offsets of that plane inside the slab
+    const char* const* tab_ptrs;                          // [world] or NULL
+    size_t tab_off_rootll, tab_off_roots, tab_off_cnt;
 };
 
 // LDS carve of the bookkeeping prologue (arrays of length N rounded up to a multiple of 4)
@@ -542,6 +546,12 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
         const int32_t* ro = a.roots_old + (size_t)anc * N;
         const int32_t* co = a.cnt_old + (size_t)anc * N;
         const double* rl = a.rootll_old + (size_t)anc * N;
+        if (a.tab_ptrs) {                              // the owner of the ancestor holds its rows
+            const char* base = a.tab_ptrs[anc / a.Kloc];
+            ro = reinterpret_cast<const int32_t*>(base + a.tab_off_roots) + (size_t)anc * N;
+            co = reinterpret_cast<const int32_t*>(base + a.tab_off_cnt) + (size_t)anc * N;
+            rl = reinterpret_cast<const double*>(base + a.tab_off_rootll) + (size_t)anc * N;
+        }
         #pragma unroll 1
         for (int i = lane; i < n; i += 64) { L.ro[i] = ro[i]; L.co[i] = co[i]; L.anc_ll[i] = rl[i]; }
         if (lane == 0) {
@@ -705,7 +715,7 @@ __global__ __launch_bounds__(PK_COLS) void pk_materialize_rank(const pk_rank_arg
 // replicated integer state (root tables) is advanced.
 __global__ __launch_bounds__(64) void pk_rank_book(const pk_rank_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int kg = blockIdx.x;
+    const int kg = a.tab_ptrs ? a.k0 + blockIdx.x : blockIdx.x;      // local bookkeeping: this rank's particles only
     const pk_book_lds L = pk_book_carve(smem, a.N);
     const bool local = kg >= a.k0 && kg < a.k0 + a.Kloc;
     pk_book_particle(a, kg, local, L);

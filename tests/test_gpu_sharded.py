@@ -44,10 +44,13 @@ def run_world(world, K, dataset, seed, jc, n_sweeps=1, transport='hostshm', extr
         return outs
 
 
-@pytest.mark.parametrize("world,K,jc", [(2, 64, True), (3, 96, False)])
-def test_sharded_sweep_bit_identical(world, K, jc):
+@pytest.mark.parametrize("world,K,jc,replicated", [(2, 64, True, False), (3, 96, False, False), (2, 64, False, True)])
+def test_sharded_sweep_bit_identical(world, K, jc, replicated):
+    """Default: every rank advances only its own particles' root tables and reads an adopted ancestor's rows from the
+    owner's slab (peer mapping); PHYLO_REPLICATED_BOOK=1: every rank advances all K tables redundantly."""
     dataset, seed, n_sweeps = 'primate_data', 4, 2
-    parts = run_world(world, K, dataset, seed, jc, n_sweeps=n_sweeps)
+    parts = run_world(world, K, dataset, seed, jc, n_sweeps=n_sweeps,
+                      extra_env={'PHYLO_REPLICATED_BOOK': '1'} if replicated else None)
     g = load_dataset(dataset)['genome']
     N = g.shape[0]
     Q = O.jc_Q() if jc else O.get_Q(O.init_y_q())

@@ -1,5 +1,5 @@
 """The N > 1 path on CPU: world_size-2 processes over torch.distributed (gloo) run the sharded protocol
-(oracle/sharded_ref.py: replicated integer state, one all-gather of three K-vectors per rank event, remote
+(oracle/sharded_ref.py: root tables replicated or kept by their owner, one all-gather of three K-vectors per rank event, remote
 nodes fetched from their owner only when merged) and must reproduce the unsharded oracle sweep; also the
 file rendezvous that hands the RCCL id to the ranks."""
 import os
@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _worker(rank, world, port, K, seed, tmp):
+def _worker(rank, world, port, K, seed, tmp, local_tables):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -43,6 +43,11 @@ def _worker(rank, world, port, K, seed, tmp):
             dist.all_gather(out, t)
             return [o.numpy() for o in out]
 
+        def gather_tables(self, mine):
+            objs = [None] * world
+            dist.all_gather_object(objs, mine)
+            return objs
+
         def serve_begin(self, pool):
             # exchange every rank's full pool (small test sizes) so that fetch_node can be answered locally
             objs = [None] * world
@@ -58,7 +63,7 @@ def _worker(rank, world, port, K, seed, tmp):
     g = load_dataset('primate_data_wang')['genome'][:, :120]
     N = g.shape[0]
     Q, pi, lam = O.get_Q(O.init_y_q()), np.full((1, 4), 0.25), np.full(N - 1, 10.0)
-    out = sweep_sharded(Comm(), rank, world, g, Q, pi, lam, lam, K, seed)
+    out = sweep_sharded(Comm(), rank, world, g, Q, pi, lam, lam, K, seed, local_tables=local_tables)
     ref = O.sweep(g, Q, pi, lam, lam, K, seed)
     np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
     np.testing.assert_allclose(out['log_weights'], ref['log_weights'], rtol=1e-12)
@@ -68,11 +73,11 @@ def _worker(rank, world, port, K, seed, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,seed", [(16, 0), (24, 3)])
-def test_sharded_protocol_world2(K, seed):
+@pytest.mark.parametrize("K,seed,local_tables", [(16, 0, False), (24, 3, True)])
+def test_sharded_protocol_world2(K, seed, local_tables):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() * 7 + K) % 1000
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(2, port, K, seed, tmp), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, K, seed, tmp, local_tables), nprocs=2, join=True)
         fetched = sum(int(np.load(os.path.join(tmp, 'fetch%d.npy' % r))[0]) for r in range(2))
         assert fetched > 0, "the test never exercised a remote child"
