@@ -120,7 +120,8 @@ def main():
         c.set_model(Q, pi, lam, lam, jc69_closed_form=a.jcmodel)
         ctxs.append(c)
     ctx = ctxs[0]
-    if world > 1:
+    sharded = world > 1 or bool(os.environ.get('PHYLO_COMM_FORCE_RCCL'))   # the env: rehearse the sharded loop on one rank
+    if sharded:
         cid = exchange_comm_id(rank, world, _ffi.comm_unique_id if rank == 0 else None)
         ctx.comm_init(rank, world, cid)
         for c in ctxs[1:]:                            # further sweeps in flight: same communicator, one comm stream
@@ -129,19 +130,22 @@ def main():
     sweep_flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if a.twisting else 0)
 
     def run(n, seed0):
-        if world == 1 or n_streams == 1:
+        if not sharded or n_streams == 1:
             for s in range(n):
                 ctxs[s % n_streams].sweep_async(seed0 + s, flags=sweep_flags, M=a.M)
         else:
-            # sharded: the sweeps in flight advance rank event by rank event (A0 B0 C0 A1 B1 C1 ...), so every rank
-            # issues the collectives of the shared communicator in the same order while the other sweeps compute
+            # sharded: the sweeps in flight advance rank event by rank event, so every rank issues the collectives of
+            # the shared communicator in the same order, fused into one grouped all-gather per rank event
             for s0 in range(0, n, n_streams):
                 group = ctxs[:min(n_streams, n - s0)]
                 for i, c in enumerate(group):
                     c.sweep_begin(seed0 + s0 + i, flags=sweep_flags, M=a.M)
                 for _ in range(N - 1):
-                    for c in group:
-                        c.sweep_step()
+                    if os.environ.get('PHYLO_BENCH_UNGROUPED'):
+                        for c in group:                   # one collective per sweep and rank event
+                            c.sweep_step()
+                    else:                                 # one grouped all-gather per rank event for the whole group
+                        _ffi.sweep_step_group(group)
                 for c in group:
                     c.sweep_finish()
         for c in ctxs:

@@ -144,6 +144,9 @@ int phylo_synchronize(phylo_ctx* ctx);
  * sweeps run underneath them. */
 int phylo_sweep_begin(phylo_ctx* ctx, uint64_t seed, uint32_t flags, int M);
 int phylo_sweep_step(phylo_ctx* ctx);
+/* One rank event of n sweeps that are at the same rank event and share one communicator: the kernels of each on its
+ * own stream, then ONE grouped all-gather for all of them, then each sweep's scan. */
+int phylo_sweep_step_group(phylo_ctx** ctxs, int n);
 int phylo_sweep_finish(phylo_ctx* ctx);
 
 /* Partial-likelihood vector of the node created at rank event r by particle slot k in the last sweep,

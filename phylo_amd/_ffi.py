@@ -26,7 +26,7 @@ EXPORTS = [
     "phylo_version", "phylo_last_error", "phylo_device_count", "phylo_create", "phylo_destroy",
     "phylo_set_leaves", "phylo_set_model", "phylo_expm_batched", "phylo_cond_likelihood_K",
     "phylo_forest_loglik", "phylo_tree_loglik", "phylo_resample", "phylo_log_zsmc", "phylo_sweep",
-    "phylo_sweep_async", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_finish", "phylo_sweep_fetch",
+    "phylo_sweep_async", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_step_group", "phylo_sweep_finish", "phylo_sweep_fetch",
     "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
     "phylo_math_probe",
     "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_max", "phylo_comm_barrier",
@@ -255,6 +255,14 @@ class Context:
 
     def comm_barrier(self):
         self._check(self._lib.phylo_comm_barrier(self._h))
+
+
+def sweep_step_group(ctxs):
+    """One rank event of several sweeps in flight (same rank event, one shared communicator): one grouped collective."""
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    rc = load().phylo_sweep_step_group(arr, C.c_int(len(ctxs)))
+    if rc != PHYLO_OK:
+        raise PhyloError(rc, (load().phylo_last_error(None) or b"").decode())
 
 
 def comm_unique_id():

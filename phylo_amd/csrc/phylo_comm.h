@@ -218,6 +218,44 @@ inline int phylo_comm_allgather_inplace(phylo_comm& me, double* const* arrays, i
     return phylo_shm_barrier(&c, err);
 }
 
+// The same all-gather for several contexts that share one communicator, as ONE grouped collective: arrays holds
+// n_arrays pointers per context, counts[i] = per-rank elements of context i's arrays.  RCCL: every context's stream
+// is joined into the communicator's stream, one ncclGroup carries all the all-gathers, every stream waits for it.
+inline int phylo_comm_allgather_group(phylo_comm* const* comms, double* const* arrays, int n_arrays, const size_t* counts,
+                                      const hipStream_t* streams, int n_ctx, std::string* err) {
+    phylo_comm& c = phylo_comm_link(*comms[0]);
+    if (c.transport != 1 || !c.cstream) {                  // host-mediated transport or no shared stream: one by one
+        for (int i = 0; i < n_ctx; ++i) {
+            int rc = phylo_comm_allgather_inplace(*comms[i], arrays + (size_t)i * n_arrays, n_arrays, counts[i], streams[i], err);
+            if (rc != PHYLO_OK) return rc;
+        }
+        return PHYLO_OK;
+    }
+    for (int i = 0; i < n_ctx; ++i) {
+        phylo_comm& me = *comms[i];
+        if (!me.ev_in && (hipEventCreateWithFlags(&me.ev_in, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&me.ev_out, hipEventDisableTiming) != hipSuccess))
+            return phylo_comm_fail(err, "hipEventCreate", "shared communicator");
+        if (hipEventRecord(me.ev_in, streams[i]) != hipSuccess || hipStreamWaitEvent(c.cstream, me.ev_in, 0) != hipSuccess)
+            return phylo_comm_fail(err, "hipStreamWaitEvent", "grouped all-gather (in)");
+    }
+    ncclResult_t r = ncclGroupStart();
+    for (int i = 0; i < n_ctx && r == ncclSuccess; ++i)
+        for (int a = 0; a < n_arrays && r == ncclSuccess; ++a) {
+            double* p = arrays[(size_t)i * n_arrays + a];
+            r = ncclAllGather(p + (size_t)c.rank * counts[i], p, counts[i], ncclDouble, c.nccl, c.cstream);
+        }
+    ncclResult_t r2 = ncclGroupEnd();
+    if (r != ncclSuccess || r2 != ncclSuccess)
+        return phylo_comm_fail(err, "ncclAllGather (group)", ncclGetErrorString(r != ncclSuccess ? r : r2));
+    phylo_comm& first = *comms[0];
+    if (hipEventRecord(first.ev_out, c.cstream) != hipSuccess) return phylo_comm_fail(err, "hipEventRecord", "grouped all-gather (out)");
+    for (int i = 0; i < n_ctx; ++i)
+        if (hipStreamWaitEvent(streams[i], first.ev_out, 0) != hipSuccess)
+            return phylo_comm_fail(err, "hipStreamWaitEvent", "grouped all-gather (out)");
+    return PHYLO_OK;
+}
+
 // all-gather of small host blobs (IPC handles) through a device bounce buffer
 inline int phylo_comm_allgather_host(phylo_comm& c, const void* mine, size_t bytes, void* all, hipStream_t stream,
                                      std::string* err) {   // c may be a sharer: rank/world are mirrored, the link is resolved below

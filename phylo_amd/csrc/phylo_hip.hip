@@ -691,7 +691,9 @@ int phylo_sweep_begin(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     return PHYLO_OK;
 }
 
-int phylo_sweep_step(phylo_ctx* c) {
+// phase 0: the whole rank event; 1: up to and including the merge; 2: what follows the all-gather of the rank
+// event's three K-vectors (phylo_sweep_step_group issues that collective once for several sweeps)
+static int sweep_step_impl(phylo_ctx* c, int phase) {
     CHK(bind(c));
     if (!c->run.active) return fail(c, PHYLO_ESTATE, "phylo_sweep_step without phylo_sweep_begin");
     const int N = c->N, K = c->K, Kl = c->Kloc, S = c->S, R = N - 1;
@@ -705,8 +707,8 @@ int phylo_sweep_step(phylo_ctx* c) {
     const size_t plane = (size_t)K * N;
     const int r = c->run.next_r;
     const double ll_tilde0 = pm_log(1.0 / (double)K);      // vcsmc.py:422
-    {
-        const int cur = r & 1, nxt = cur ^ 1;
+    const int cur = r & 1, nxt = cur ^ 1;
+    if (phase != 2) {
         pk_rank_args b{};
         b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
         b.seed = seed; b.flags = flags;
@@ -809,10 +811,18 @@ int phylo_sweep_step(phylo_ctx* c) {
             hipLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
         CHK(launch_check(c, "pk_rank_merge"));
         ++launches;
+    }
+    if (phase == 0 && c->comm.transport != 0) {
+        double* rows[3] = {c->d_logw + (size_t)r * K, c->d_ll + (size_t)r * K, c->d_nodell + N + (size_t)r * K};
+        CHK(phylo_comm_allgather_inplace(c->comm, rows, 3, (size_t)Kl, c->stream, &c->err));
+    }
+    if (phase == 1) {
+        c->run.launches += launches;
+        return PHYLO_OK;
+    }
+    {
         {
             if (c->comm.transport != 0) {
-                double* rows[3] = {c->d_logw + (size_t)r * K, c->d_ll + (size_t)r * K, c->d_nodell + N + (size_t)r * K};
-                CHK(phylo_comm_allgather_inplace(c->comm, rows, 3, (size_t)Kl, c->stream, &c->err));
                 if (!c->run.local_book) {
                     hipLaunchKernelGGL(pk_fix_rootll, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, c->d_rootll[nxt],
                                        (const double*)(c->d_nodell + N + (size_t)r * K), K, N, N - r, c->k0, Kl);
@@ -831,6 +841,46 @@ int phylo_sweep_step(phylo_ctx* c) {
     }
     c->run.launches += launches;
     ++c->run.next_r;
+    return PHYLO_OK;
+}
+
+int phylo_sweep_step(phylo_ctx* c) { return sweep_step_impl(c, 0); }
+
+int phylo_sweep_step_group(phylo_ctx** ctxs, int n) {
+    if (!ctxs || n < 1) return fail(nullptr, PHYLO_EINVAL, "phylo_sweep_step_group needs at least one context");
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i]) return fail(nullptr, PHYLO_EINVAL, "NULL context");
+    if (n == 1 || ctxs[0]->comm.transport == 0) {          // nothing to fuse
+        for (int i = 0; i < n; ++i) CHK(sweep_step_impl(ctxs[i], 0));
+        return PHYLO_OK;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]->run.active || ctxs[i]->run.next_r != ctxs[0]->run.next_r)
+            return fail(ctxs[i], PHYLO_ESTATE, "the sweeps of a group must be at the same rank event");
+        if (&phylo_comm_link(ctxs[i]->comm) != &phylo_comm_link(ctxs[0]->comm))
+            return fail(ctxs[i], PHYLO_EINVAL, "the contexts of a group must share one communicator (phylo_comm_share)");
+    }
+    for (int i = 0; i < n; ++i) CHK(sweep_step_impl(ctxs[i], 1));
+    std::vector<phylo_comm*> comms(n);
+    std::vector<double*> rows((size_t)3 * n);
+    std::vector<hipStream_t> streams(n);
+    for (int i = 0; i < n; ++i) {
+        phylo_ctx* c = ctxs[i];
+        const size_t r = (size_t)c->run.next_r, K = c->K;
+        comms[i] = &c->comm;
+        streams[i] = c->stream;
+        rows[3 * i] = c->d_logw + r * K;
+        rows[3 * i + 1] = c->d_ll + r * K;
+        rows[3 * i + 2] = c->d_nodell + c->N + r * K;
+    }
+    {
+        phylo_ctx* c0 = ctxs[0];
+        std::vector<size_t> counts(n);
+        for (int i = 0; i < n; ++i) counts[i] = (size_t)ctxs[i]->Kloc;
+        int rc = phylo_comm_allgather_group(comms.data(), rows.data(), 3, counts.data(), streams.data(), n, &c0->err);
+        if (rc != PHYLO_OK) { g_last_error = c0->err; return rc; }
+    }
+    for (int i = 0; i < n; ++i) CHK(sweep_step_impl(ctxs[i], 2));
     return PHYLO_OK;
 }
 

@@ -46,8 +46,11 @@ def main():
             for i, c in enumerate(group):
                 c.sweep_begin(seed + i, flags=flags, M=max(twist_M, 1))
             for _ in range(N - 1):
-                for c in group:
-                    c.sweep_step()
+                if os.environ.get('PHYLO_TEST_GROUP_STEP'):
+                    _ffi.sweep_step_group(group)      # one grouped collective per rank event (bench.py's loop)
+                else:
+                    for c in group:
+                        c.sweep_step()
             for c in group:
                 c.sweep_finish()
         first = ctx.sweep_fetch()

@@ -118,7 +118,9 @@ def test_rccl_single_rank_world():
 
 @pytest.mark.parametrize("transport,world,extra", [
     ('hostshm', 2, {}),                                   # two processes on GPU 0, three sweeps in flight each
+    ('hostshm', 2, {'PHYLO_TEST_GROUP_STEP': '1'}),
     ('rccl', 1, {'PHYLO_COMM_FORCE_RCCL': '1'}),          # the real library on its dedicated comm stream
+    ('rccl', 1, {'PHYLO_COMM_FORCE_RCCL': '1', 'PHYLO_TEST_GROUP_STEP': '1'}),   # ... one grouped all-gather per rank event
 ])
 def test_sweeps_in_flight_share_one_communicator(transport, world, extra):
     """bench.py's sharded loop: contexts joined by phylo_comm_share advance rank event by rank event; every sweep
