@@ -27,8 +27,9 @@ def one(pattern):
 lines = ["# rocprofv3 summary, round %s" % tag, "",
          "Command: `python bench.py --steps 30 --warmup 3 --no-cpu-baseline` (primate.p N=12 S=898, GTR-init, K=2048;",
          "default = 3 sweeps in flight; `--streams 1` = one sweep at a time; `twist` = `--twisting --M 1 --streams 1`;",
-         "`ds1` = `--dataset hohna_data_1 --n_particles 4096 --streams 1`).  Raw tables: `%s_kernel_stats_*.csv`." % tag, ""]
-for name in ("default", "1stream", "twist", "ds1"):
+         "`ds1` = `--dataset hohna_data_1 --n_particles 4096 --streams 1`; `train` = `python tools/train_probe.py --steps 10`:",
+         "VI training steps, sweep with the graph kept + reverse pass, pg_* kernels).  Raw tables: `%s_kernel_stats_*.csv`." % tag, ""]
+for name in ("default", "1stream", "twist", "ds1", "train"):
     st = one("trace_%s/*/*_kernel_stats.csv" % name)
     if not st:
         continue
@@ -42,6 +43,11 @@ for name in ("default", "1stream", "twist", "ds1"):
     if js:
         j = json.loads(js[-1])
         lines += ["", "bench line under the profiler: value %.4g %s, ms_per_step %.4f" % (j['value'], j['unit'], j['ms_per_step']), ""]
+    tj = [l for l in log.splitlines() if l.startswith('{"dataset"')]
+    if tj:
+        j = json.loads(tj[-1])
+        lines += ["", "training step under the profiler: forward %.3f ms, reverse pass %.3f ms, step wall %.3f ms (K=%d, %d sites)"
+                  % (j['forward_ms'], j['backward_ms'], j['step_wall_ms'], j['K'], j['sites']), ""]
 
 agg = {}
 for cn, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
