@@ -134,7 +134,8 @@ PM_HD pm_lp pm_lp_init() { pm_lp a = {1.0, 0, 0.0}; return a; }
 PM_HD void pm_lp_mul(pm_lp& a, double x) {
     const uint64_t bx = pm_bits(x);
     const int ex = (int)((bx >> 52) & 0x7ff);
-    if ((bx >> 63) || ex == 0 || ex == 0x7ff) {
+    // negative, zero / subnormal, inf / nan: everything outside the positive normal range, in ONE unsigned compare
+    if (bx - 0x0010000000000000ull >= 0x7fe0000000000000ull) {
         a.extra = a.extra + pm_log(x);
         return;
     }
