@@ -179,6 +179,9 @@ int phylo_comm_init(phylo_ctx* ctx, int rank, int world, const char id[PHYLO_COM
  * own: all collectives of the process then run on one stream of one communicator, in host issue order.  Collective
  * (peer pools are mapped); every rank makes the call for its contexts in the same order.  `owner` must outlive ctx. */
 int phylo_comm_share(phylo_ctx* ctx, phylo_ctx* owner);
+/* All-gather of a host blob of `bytes` bytes per rank (all = world * bytes, rank order): how a sharded caller
+ * assembles per-particle outputs (ancestors, merges, branches) for host-side tree reconstruction. */
+int phylo_comm_allgather(phylo_ctx* ctx, const void* mine, size_t bytes, void* all);
 int phylo_comm_max(phylo_ctx* ctx, double* value);
 int phylo_comm_barrier(phylo_ctx* ctx);
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "phylo_sweep_async", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_step_group", "phylo_sweep_finish", "phylo_sweep_fetch",
     "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
     "phylo_math_probe",
-    "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_max", "phylo_comm_barrier",
+    "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_allgather", "phylo_comm_max", "phylo_comm_barrier",
 ]
 
 
@@ -247,6 +247,16 @@ class Context:
         world = owner.K // owner.K_local
         self.K_local = self.K // world
         self.k0 = (owner.k0 // owner.K_local) * self.K_local
+
+    def comm_allgather_columns(self, a):
+        """a: [..., K_local] on every rank -> [..., K] (rank order = particle order).  Collective."""
+        a = np.ascontiguousarray(a)
+        world = self.K // self.K_local
+        if world == 1:
+            return a
+        out = np.empty((world,) + a.shape, dtype=a.dtype)
+        self._check(self._lib.phylo_comm_allgather(self._h, _ptr(a), C.c_size_t(a.nbytes), _ptr(out)))
+        return np.concatenate(list(out), axis=-1)
 
     def comm_max(self, value):
         v = C.c_double(float(value))

@@ -1197,6 +1197,13 @@ int phylo_comm_max(phylo_ctx* c, double* value) {
     return phylo_comm_allreduce_max(c->comm, value, c->stream, &c->err);
 }
 
+int phylo_comm_allgather(phylo_ctx* c, const void* mine, size_t bytes, void* all) {
+    CHK(bind(c));
+    if (!mine || !all || bytes == 0) return fail(c, PHYLO_EINVAL, "bad arguments to phylo_comm_allgather");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return phylo_comm_allgather_host(c->comm, mine, bytes, all, c->stream, &c->err);
+}
+
 int phylo_comm_barrier(phylo_ctx* c) {
     double v = 0.0;
     return phylo_comm_max(c, &v);

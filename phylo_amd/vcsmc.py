@@ -96,8 +96,23 @@ class VCSMC:
     # ---- device context -----------------------------------------------------------------------------
     def _context(self):
         if self._ctx is None:
+            n_gpus = int(getattr(self.args, 'n_gpus', 1) or 1)
+            if n_gpus > 1:
+                # one process per GPU (python -m torch.distributed.run --nproc-per-node N runner.py --n_gpus N ...):
+                # the K particles are sharded over the ranks, resampling stays global
+                import os
+                from .rendezvous import exchange_comm_id
+                world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+                if world != n_gpus:
+                    raise RuntimeError("--n_gpus %d needs %d ranks (python -m torch.distributed.run --nproc-per-node %d ...), "
+                                       "found WORLD_SIZE=%d" % (n_gpus, n_gpus, n_gpus, world))
+                self._device = int(os.environ.get('LOCAL_RANK', '0')) % max(_ffi.device_count(), 1)
+                self._rank, self._world = rank, world
             ctx = _ffi.Context(self.K, self.N, self.S, self.A, device=self._device)
             ctx.set_leaves(self.genome_NxSxA)
+            if n_gpus > 1:
+                cid = exchange_comm_id(self._rank, self._world, _ffi.comm_unique_id if self._rank == 0 else None)
+                ctx.comm_init(self._rank, self._world, cid)
             self._ctx = ctx
         self._ctx.set_model(self.Qmatrix, self.stationary_probs, self.left_branches_param, self.right_branches_param,
                             jc69_closed_form=bool(self.args.jcmodel))
@@ -181,7 +196,13 @@ class VCSMC:
         self._twisted = bool(flags & _ffi.TWISTING)
         seed = self.seed + self._sweeps if seed is None else int(seed)
         self._sweeps += 1
-        out = self._context().sweep(seed, flags=flags, M=self.M)
+        ctx = self._context()
+        out = ctx.sweep(seed, flags=flags, M=self.M)
+        if ctx.K_local != ctx.K:                         # sharded: every rank assembles all K particles' outputs
+            for key in ('log_weights', 'log_likelihood', 'left_branches', 'right_branches', 'ancestors'):
+                out[key] = ctx.comm_allgather_columns(out[key])
+            out['merges'] = np.ascontiguousarray(
+                np.moveaxis(ctx.comm_allgather_columns(np.moveaxis(out['merges'], 1, 2)), 2, 1))
         self.log_weights = out['log_weights']            # rows 1..N-1 of the reference's tensor
         self.log_likelihood = out['log_likelihood']
         self.left_branches = out['left_branches']
@@ -297,6 +318,7 @@ class VCSMC:
         print('================= Dataset shape: KxNxSxA =================')
         print((self.K, self.N, self.S, self.A))
         print('==========================================================')
+        self._context()                                    # fixes the device (and joins the ranks when --n_gpus > 1)
         self.optimizer = train_mod.make_optimizer(getattr(self.args, 'optimizer', ''), self.lr)   # vcsmc.py:488-491
         nested = bool(getattr(self.args, 'nested', False))
         trainer = None
@@ -346,7 +368,7 @@ class VCSMC:
                 trainer.close()
         print("Done training.")
         self.elbos = np.asarray(elbos)
-        if save_dir is not None:
+        if save_dir is not None and getattr(self, '_rank', 0) == 0:   # sharded: every rank holds the same results; rank 0 writes
             if save_dir == 'auto':                   # vcsmc.py:504-507
                 tm = str(datetime.now())
                 save_dir = './results/' + str(getattr(self.args, 'dataset', 'data')) + '/' + str(getattr(self.args, 'nested', False)) + \

@@ -181,3 +181,35 @@ def test_comm_init_rejects_bad_world():
     with pytest.raises(_ffi.PhyloError):
         ctx.comm_init(0, 3, b'\0' * 128)          # K not divisible by world
     ctx.close()
+
+
+def test_runner_n_gpus_equals_single_process():
+    """`runner.py --n_gpus 2` (two processes on GPU 0, hostshm): the particles are sharded for the evaluation sweeps,
+    every rank takes the same optimiser steps, and ELBOs, parameters and trees equal the one-process run."""
+    argv = ['--dataset', 'primate_data_wang', '--n_particles', '32', '--num_epoch', '2', '--batch_size', '256',
+            '--optimizer', 'Adam', '--learning_rate', '0.05', '--seed', '4']
+    outs = {}
+    for world in (1, 2):
+        with tempfile.TemporaryDirectory() as tmp:
+            env = dict(os.environ, PHYLO_RDZV_DIR=tmp, MASTER_PORT=str(29100 + os.getpid() % 800 + world), PHYLO_COMM='hostshm')
+            procs = []
+            for r in range(world):
+                out = os.path.join(tmp, "w%d.npz" % r)
+                cmd = [sys.executable, os.path.join(ROOT, "tests", "_runner_worker.py"), str(r), str(world), out, '--'] + argv + \
+                      ['--n_gpus', str(world)]
+                procs.append((out, subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            res = []
+            for out, p in procs:
+                log, _ = p.communicate(timeout=240)
+                assert p.returncode == 0, log.decode()[-2000:]
+                res.append(dict(np.load(out)))
+            if world == 2:
+                assert os.path.exists(os.path.join(tmp, 'results', 'results.p'))
+            outs[world] = res
+    one, two = outs[1][0], outs[2]
+    for r in two:
+        assert np.array_equal(r['elbos'], one['elbos'])
+        assert np.array_equal(r['lam'], one['lam'])
+        assert str(r['newick']) == str(one['newick'])
+        assert np.array_equal(r['log_weights'].view(np.uint64), one['log_weights'].view(np.uint64))
+        np.testing.assert_array_equal(r['ancestors'], one['ancestors'])
