@@ -104,6 +104,7 @@ class Trainer:
         N = self.genome.shape[0]
         self.ctx = _ffi.Context(K, N, int(batch_sites), device=device)
         self.last = None
+        self._sites = None
 
     def close(self):
         self.ctx.close()
@@ -111,7 +112,10 @@ class Trainer:
     def gradients(self, sites, seed):
         """Sweep over genome[:, sites] and its gradient w.r.t. the variables.  Returns (logZ, grads, raw)."""
         Q, pi, lam_l, lam_r = self.v.evaluate()
-        self.ctx.set_leaves(self.genome[:, sites, :])
+        sites = np.asarray(sites)
+        if self._sites is None or not np.array_equal(sites, self._sites):   # the slice on the device is still this one
+            self.ctx.set_leaves(self.genome[:, sites, :])
+            self._sites = sites.copy()
         self.ctx.set_model(Q, pi, lam_l, lam_r, jc69_closed_form=self.v.jc)
         self.ctx.sweep_async(int(seed), self.flags)
         out = self.ctx.sweep_fetch(arrays=False)
