@@ -3,7 +3,10 @@
 
 A "step" is one full sweep (N-1 rank events: draws, transition matrices, resampling, Felsenstein
 merges, weights, log Z-hat) over the alignment already resident in HBM.  Default workload: primate.p
-(N=12, S=898), jcmodel=false initial Q (GTR-init), K=2048 particles per GPU.
+(N=12, S=898), jcmodel=false initial Q (GTR-init), K=2048 particles per GPU.  Throughput form on one GPU:
+independent sweeps (own seed, own resampling, own log Z-hat, each bit-identical to the sweep run alone) are issued
+three per set of launches (phylo_sweep_batch_async) on three contexts in flight; `single_sweep_ms` is the
+latency of one sweep alone.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -42,6 +45,9 @@ def parse():
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--streams', type=int, default=0,
                    help='independent sweeps kept in flight on separate HIP streams (0 = 3 on one GPU, 1 when sharded)')
+    p.add_argument('--batch', type=int, default=0,
+                   help='independent sweeps per set of launches (phylo_sweep_batch_async); 0 = 3 on one GPU with the plain '
+                        'proposal, 1 otherwise')
     p.add_argument('--twisting', action='store_true', help='twisted proposal (vncsmc.py); BASELINE config 2')
     p.add_argument('--M', type=int, default=1, help='sub-samples of the twisted proposal')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -109,13 +115,18 @@ def main():
     ndev = _ffi.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    sharded_env = world > 1 or bool(os.environ.get('PHYLO_COMM_FORCE_RCCL'))
+    # batching keeps every node (no lazy nodes): it pays where launches are short, i.e. below the lazy-node threshold
+    batch = a.batch if a.batch > 0 else (3 if not (sharded_env or a.twisting) and S < 8192 else 1)
+    if batch > 1 and (sharded_env or a.twisting):
+        raise SystemExit("--batch needs one GPU and the plain proposal")
     n_streams = a.streams if a.streams > 0 else 3
-    pool_bytes = 32.0 * (N - 1) * a.n_particles * S   # node pool of one context
+    pool_bytes = 32.0 * (N - 1) * a.n_particles * batch * S   # node pool of one context
     while n_streams > 1 and n_streams * pool_bytes > 200e9:
         n_streams -= 1                                # every sweep in flight owns a pool; stay inside 288 GB of HBM
     ctxs = []
     for i in range(n_streams):
-        c = _ffi.Context(K_global, N, S, device=local_rank % ndev)
+        c = _ffi.Context(K_global * batch, N, S, device=local_rank % ndev)
         c.set_leaves(g)
         c.set_model(Q, pi, lam, lam, jc69_closed_form=a.jcmodel)
         ctxs.append(c)
@@ -128,9 +139,22 @@ def main():
             c.comm_share(ctx)
 
     sweep_flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if a.twisting else 0)
+    single = ctx
+    if batch > 1:                                     # one K-particle context: remainder sweeps, single-sweep latency
+        single = _ffi.Context(K_global, N, S, device=local_rank % ndev)
+        single.set_leaves(g)
+        single.set_model(Q, pi, lam, lam, jc69_closed_form=a.jcmodel)
 
     def run(n, seed0):
-        if not sharded or n_streams == 1:
+        if batch > 1:
+            # `batch` independent sweeps per set of launches, contexts round-robin; a remainder runs as single sweeps
+            nb = n // batch
+            for i in range(nb):
+                ctxs[i % n_streams].sweep_batch_async([seed0 + i * batch + j for j in range(batch)], flags=sweep_flags)
+            for j in range(n - nb * batch):
+                single.sweep_async(seed0 + nb * batch + j, flags=sweep_flags, M=a.M)
+            single.synchronize()
+        elif not sharded or n_streams == 1:
             for s in range(n):
                 ctxs[s % n_streams].sweep_async(seed0 + s, flags=sweep_flags, M=a.M)
         else:
@@ -158,19 +182,28 @@ def main():
     ctx.comm_barrier()
     dt = time.perf_counter() - t0
     dt = ctx.comm_max(dt)                            # max over ranks
-    last = ctxs[(a.steps - 1) % n_streams].sweep_fetch(arrays=False)
+    if batch > 1:
+        nb = a.steps // batch
+        last = single.sweep_fetch(arrays=False) if a.steps % batch else ctxs[(nb - 1) % n_streams].sweep_fetch(arrays=False)
+        if a.steps % batch == 0:
+            last['logZ'] = float(ctxs[(nb - 1) % n_streams].sweep_fetch_logz(batch)[-1])
+    else:
+        last = ctxs[(a.steps - 1) % n_streams].sweep_fetch(arrays=False)
 
     # one sweep at a time on one stream (latency of a single sweep), and the dominant kernel (the
     # Felsenstein merge): average launch duration from HIP events on the ctx stream, nothing else in flight
     t1 = time.perf_counter()
     for s in range(10):
-        ctx.sweep_async(a.seed + s, flags=sweep_flags, M=a.M)
-    ctx.synchronize()
+        single.sweep_async(a.seed + s, flags=sweep_flags, M=a.M)
+    single.synchronize()
     single_ms = (time.perf_counter() - t1) / 10 * 1e3
     prof_sweeps = 3
     merge_ms, merge_n = 0.0, 0
-    for s in range(prof_sweeps):
-        ctx.sweep_async(a.seed + s, flags=sweep_flags | _ffi.TIME_KERNELS, M=a.M)
+    for s in range(prof_sweeps):                    # the launch form of the timed region, one at a time, kernel-stamped events
+        if batch > 1:
+            ctx.sweep_batch_async([a.seed + s * batch + j for j in range(batch)], flags=sweep_flags | _ffi.TIME_KERNELS)
+        else:
+            ctx.sweep_async(a.seed + s, flags=sweep_flags | _ffi.TIME_KERNELS, M=a.M)
         st = ctx.sweep_fetch(arrays=False)['stats']
         merge_ms += st['merge_ms']
         merge_n += st['merge_launches']
@@ -200,7 +233,8 @@ def main():
                                    % (wname, N, S, ("JC69" if a.jcmodel else "GTR-init (jcmodel=false)") + (" + twisting M=%d" % a.M if a.twisting else ""),
                                       a.n_particles, K_global, N - 1),
                        "parallelism": "particles sharded over %d GPU(s), global resampling" % world,
-                       "sweeps_in_flight": n_streams},
+                       "sweeps_per_launch_set": batch, "contexts_in_flight": n_streams,
+                       "sweeps_in_flight": n_streams * batch},
             "single_sweep_ms": single_ms,
             "log_Z": last['logZ'],
             "roofline": {"bound": "hbm", "kernel": "pk_rank_merge", "achieved": achieved, "peak": HBM_PEAK_GBPS,
@@ -211,6 +245,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds, a.M if a.twisting else 0)
         print(json.dumps(line), flush=True)
+    if single is not ctx:
+        single.close()
     for c in reversed(ctxs):                          # sharers before the owner of the communicator
         c.close()
 

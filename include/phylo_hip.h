@@ -137,6 +137,14 @@ int phylo_sweep_fetch(phylo_ctx* ctx, double* log_weights, double* log_lik, doub
                       phylo_stats* perf);
 int phylo_synchronize(phylo_ctx* ctx);
 
+/* G INDEPENDENT sweeps in one set of launches (throughput form for callers that need many sweeps: minibatches,
+ * replicates): the context's K particles are G groups of K/G; group g is exactly the sweep of K/G particles with
+ * seeds[g] (own draws, own resampling, own log Z-hat).  Outputs of phylo_sweep_fetch hold group g in columns
+ * [g K/G, (g+1) K/G) (ancestors index inside the group); phylo_sweep_fetch_logz returns the G estimates.
+ * One GPU, plain proposal, eager nodes. */
+int phylo_sweep_batch_async(phylo_ctx* ctx, const uint64_t* seeds, int G, uint32_t flags);
+int phylo_sweep_fetch_logz(phylo_ctx* ctx, double* logZ_G, int G);
+
 /* The same sweep issued one rank event at a time: begin (draws, tables), N-1 x step, finish (log Z-hat).
  * phylo_sweep_async is exactly begin + steps + finish.  A caller that keeps several sweeps in flight on sharded
  * contexts interleaves them rank event by rank event (A0 B0 C0 A1 B1 C1 ...), so that the collectives of the

@@ -32,6 +32,7 @@ struct sweep_run {                       // a sweep being issued rank event by r
     uint32_t flags = 0;
     int M = 1, launches = 0, next_r = 0;
     bool twist = false, graph = false, lazy = false, timek = false, fuse_scan = false, active = false, local_book = false;
+    int G = 1;                             // independent sweeps batched in this context (phylo_sweep_batch_async)
 };
 
 struct phylo_ctx {
@@ -60,7 +61,8 @@ struct phylo_ctx {
     double *d_bl = nullptr, *d_br = nullptr, *d_Pmat = nullptr;   // [(N-1)][Kloc](x32)
     double *d_logw = nullptr, *d_ll = nullptr;                    // [(N-1)][K] (global columns)
     double* d_aux = nullptr;             // [Kloc][PK_AUX]
-    double* d_lse = nullptr;             // [N-1] + total
+    double* d_lse = nullptr;             // [PK_MAX_GROUPS][N-1 + total]; group 0 only unless sweeps are batched
+    uint64_t* d_group_seeds = nullptr;   // [PK_MAX_GROUPS]
     // root tables, two planes each, carved from ONE slab (so that peers map it with one handle):
     // rootll[0], rootll[1] (double), roots[0], roots[1], cnt[0], cnt[1] (int32), each [K][N]
     char* d_tables = nullptr;
@@ -91,6 +93,8 @@ struct phylo_ctx {
     int32_t *d_ad_off = nullptr, *d_ad_idx = nullptr, *d_par_off = nullptr, *d_par_idx = nullptr;
     int32_t *d_heavy = nullptr, *d_chunk_beg = nullptr, *d_chunk_cnt = nullptr;   // [R K], [<= 2 R K / PG_PCHUNK + 1] x2
     bool graph_ready = false, last_graph = false;
+    int last_G = 1;
+    std::vector<uint64_t> h_group_seeds;
     hipEvent_t evb0 = nullptr, evb1 = nullptr;
     phylo_stats stats{};
     sweep_run run;
@@ -188,12 +192,13 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_heavy = c->d_chunk_beg = c->d_chunk_cnt = nullptr;
     c->graph_ready = false;
     c->last_graph = false;
-    void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse,
+    void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse, c->d_group_seeds,
                     c->d_tables, (void*)c->d_tab_ptrs, c->d_child, c->d_merges, c->d_anc,
                     c->d_cdf[0], c->d_cdf[1], c->d_counter, (void*)c->d_pool_ptrs, c->d_mark, c->d_mat_list, c->d_sync};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_pool = c->d_nodell = c->d_bl = c->d_br = c->d_Pmat = c->d_logw = c->d_ll = c->d_aux = c->d_lse = nullptr;
+    c->d_group_seeds = nullptr;
     c->d_roots[0] = c->d_roots[1] = c->d_cnt[0] = c->d_cnt[1] = c->d_child = c->d_merges = nullptr;
     c->d_anc = nullptr;
     c->d_cdf[0] = c->d_cdf[1] = nullptr;
@@ -220,7 +225,8 @@ int alloc_sweep_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_logw, R * K));
     CHK(dalloc(c, &c->d_ll, R * K));
     CHK(dalloc(c, &c->d_aux, Kl * PK_AUX));
-    CHK(dalloc(c, &c->d_lse, R + 1));
+    CHK(dalloc(c, &c->d_lse, (R + 1) * PK_MAX_GROUPS));
+    CHK(dalloc(c, &c->d_group_seeds, PK_MAX_GROUPS));
     CHK(dalloc(c, &c->d_tables, 32 * K * N));
     for (int i = 0; i < 2; ++i) {
         c->d_rootll[i] = reinterpret_cast<double*>(c->d_tables) + (size_t)i * K * N;
@@ -612,9 +618,13 @@ int phylo_log_zsmc(phylo_ctx* c, const double* logw, int R, int K, double* out) 
     return PHYLO_OK;
 }
 
-int phylo_sweep_begin(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
+static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, const uint64_t* group_seeds, int G) {
     CHK(bind(c));
     c->run.active = false;
+    if (G < 1 || G > PK_MAX_GROUPS || c->K % G != 0)
+        return fail(c, PHYLO_EINVAL, "a batch needs 1 <= G <= %d sweeps and K = %d divisible by G (got %d)", PK_MAX_GROUPS, c->K, G);
+    if (G > 1 && (c->world != 1 || (flags & (PHYLO_TWISTING | PHYLO_KEEP_GRAPH))))
+        return fail(c, PHYLO_EINVAL, "batched sweeps need one GPU and the plain proposal without PHYLO_KEEP_GRAPH");
     if (!c->have_leaves || !c->have_model)
         return fail(c, PHYLO_ESTATE, "phylo_set_leaves and phylo_set_model must be called before a sweep");
     if (!c->state_ready) {
@@ -668,15 +678,17 @@ int phylo_sweep_begin(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
         CHK(ensure_graph_state(c));
     }
     const bool lazy_ok = !twist && !graph && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES");
-    const bool lazy = lazy_ok && (S >= 8192 || getenv("PHYLO_LAZY_NODES"));
+    const bool lazy = lazy_ok && ((G == 1 && S >= 8192) || getenv("PHYLO_LAZY_NODES"));
     int launches = 0;
-    const bool fuse_scan = !twist && !graph && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
+    const bool fuse_scan = !twist && !graph && G == 1 && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
     c->swept = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (lazy) HIPCHK(c, hipMemsetAsync(c->d_mark, 0, (((size_t)R * K + R + 3) & ~(size_t)3) * sizeof(unsigned int), c->stream));
     if (!twist) {
+        if (G > 1) HIPCHK(c, hipMemcpyAsync(c->d_group_seeds, group_seeds, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(pk_sweep_draws, dim3(cdiv(2L * R * Kl, 64)), dim3(64), 0, c->stream, c->d_Q, c->d_lam_l, c->d_lam_r,
-                           c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat);
+                           c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat, K / G,
+                           G > 1 ? (const uint64_t*)c->d_group_seeds : (const uint64_t*)nullptr);
         CHK(launch_check(c, "pk_sweep_draws"));
     }
     hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream,
@@ -688,8 +700,11 @@ int phylo_sweep_begin(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     c->run.seed = seed; c->run.flags = flags; c->run.M = M;
     c->run.twist = twist; c->run.graph = graph; c->run.lazy = lazy; c->run.timek = timek; c->run.fuse_scan = fuse_scan;
     c->run.launches = launches; c->run.next_r = 0; c->run.active = true;
+    c->run.G = G;
     return PHYLO_OK;
 }
+
+int phylo_sweep_begin(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) { return sweep_begin_impl(c, seed, flags, M, nullptr, 1); }
 
 // phase 0: the whole rank event; 1: up to and including the merge; 2: what follows the all-gather of the rank
 // event's three K-vectors (phylo_sweep_step_group issues that collective once for several sweeps)
@@ -706,12 +721,14 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
     const size_t lds = pk_book_lds_bytes(N);
     const size_t plane = (size_t)K * N;
     const int r = c->run.next_r;
-    const double ll_tilde0 = pm_log(1.0 / (double)K);      // vcsmc.py:422
+    const int G = c->run.G, Kg = K / G;
+    const double ll_tilde0 = pm_log(1.0 / (double)Kg);     // vcsmc.py:422
     const int cur = r & 1, nxt = cur ^ 1;
     if (phase != 2) {
         pk_rank_args b{};
         b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
         b.seed = seed; b.flags = flags;
+        b.Kg = Kg; b.group_seeds = G > 1 ? c->d_group_seeds : nullptr;
         if (graph) {                                       // every rank event keeps its tables: plane r -> plane r + 1
             b.roots_old = c->d_hroots + plane * r; b.cnt_old = c->d_hcnt + plane * r;
             b.roots_new = c->d_hroots + plane * (r + 1); b.cnt_new = c->d_hcnt + plane * (r + 1);
@@ -830,7 +847,13 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                     ++launches;
                 }
             }
-            if (!fuse_scan || twist || r + 1 == R) {           // otherwise the next rank event's launch scans these weights
+            if (G > 1) {                                       // one scan workgroup per batched sweep
+                hipLaunchKernelGGL(pk_resample_scan_groups, dim3(G), dim3(PK_COLS), pk_scan_lds_bytes(Kg), c->stream,
+                                   (const double*)(c->d_logw + (size_t)r * K), Kg, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
+                                   c->d_lse + r, R + 1);
+                CHK(launch_check(c, "pk_resample_scan_groups"));
+                ++launches;
+            } else if (!fuse_scan || twist || r + 1 == R) {    // otherwise the next rank event's launch scans these weights
                 hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream,
                                    (const double*)(c->d_logw + (size_t)r * K), K, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
                                    c->d_lse + r);
@@ -894,7 +917,10 @@ int phylo_sweep_finish(phylo_ctx* c) {
     const bool twist = c->run.twist, graph = c->run.graph, lazy = c->run.lazy, timek = c->run.timek;
     int launches = c->run.launches;
     (void)flags;
-    hipLaunchKernelGGL(pk_logz_total, dim3(1), dim3(64), 0, c->stream, (const double*)c->d_lse, R, c->d_lse + R);
+    if (c->run.G > 1)
+        hipLaunchKernelGGL(pk_logz_total_groups, dim3(c->run.G), dim3(64), 0, c->stream, c->d_lse, R, R + 1);
+    else
+        hipLaunchKernelGGL(pk_logz_total, dim3(1), dim3(64), 0, c->stream, (const double*)c->d_lse, R, c->d_lse + R);
     CHK(launch_check(c, "pk_logz_total"));
     ++launches;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
@@ -902,6 +928,7 @@ int phylo_sweep_finish(phylo_ctx* c) {
     c->run.active = false;
     c->last_lazy = lazy;
     c->last_graph = graph;
+    c->last_G = c->run.G;
     c->n_merge_events = timek ? R : 0;
     c->stats.n_launches = launches;
     c->stats.units = (double)Kl * S * R;
@@ -918,6 +945,27 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     CHK(phylo_sweep_begin(c, seed, flags, M));
     for (int r = 0; r < c->N - 1; ++r) CHK(phylo_sweep_step(c));
     return phylo_sweep_finish(c);
+}
+
+int phylo_sweep_batch_async(phylo_ctx* c, const uint64_t* seeds, int G, uint32_t flags) {
+    if (!c) return fail(nullptr, PHYLO_EINVAL, "ctx is NULL");
+    if (!seeds) return fail(c, PHYLO_EINVAL, "seeds is NULL");
+    c->h_group_seeds.assign(seeds, seeds + (G > 0 ? G : 0));          // stays alive until the copy has run
+    CHK(sweep_begin_impl(c, G > 0 ? seeds[0] : 0, flags, 1, c->h_group_seeds.data(), G));
+    for (int r = 0; r < c->N - 1; ++r) CHK(phylo_sweep_step(c));
+    return phylo_sweep_finish(c);
+}
+
+int phylo_sweep_fetch_logz(phylo_ctx* c, double* logZ, int G) {
+    CHK(bind(c));
+    if (!c->swept) return fail(c, PHYLO_ESTATE, "no sweep has been run");
+    if (!logZ || G != c->last_G) return fail(c, PHYLO_EINVAL, "the last sweep batched %d sweep(s), asked for %d", c->last_G, G);
+    const size_t R = (size_t)c->N - 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<double> all((R + 1) * G);
+    HIPCHK(c, hipMemcpy(all.data(), c->d_lse, all.size() * 8, hipMemcpyDeviceToHost));
+    for (int g = 0; g < G; ++g) logZ[g] = all[g * (R + 1) + R];
+    return PHYLO_OK;
 }
 
 int phylo_synchronize(phylo_ctx* c) {

@@ -9,6 +9,7 @@
 #define PK_COLS 256          // canonical site-sum columns == threads per merge workgroup
 #define PK_AUX 8             // per-particle scalars handed from the bookkeeping kernel to the merge epilogue
 #define PK_MAX_TAXA 512
+#define PK_MAX_GROUPS 64                 // independent sweeps batched in one context
 
 // aux slots
 enum { AUX_SUM_REM = 0, AUX_FPRIOR, AUX_LPRIOR, AUX_RPRIOR, AUX_LL_TILDE, AUX_PAREN, AUX_LOGV, AUX_Q };
@@ -100,12 +101,14 @@ __global__ __launch_bounds__(64) void pk_expm_batched(const double* __restrict__
 __global__ __launch_bounds__(64) void pk_sweep_draws(const double* __restrict__ Q, const double* __restrict__ lam_l,
                                                      const double* __restrict__ lam_r, int jc, uint64_t seed, int R, int K,
                                                      int k0, double* __restrict__ bl, double* __restrict__ br,
-                                                     double* __restrict__ Pmat) {
+                                                     double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * R * K) return;
     const int side = t & 1, i = t >> 1;
     const int r = i / K, k = i - r * K;
-    const pm_u32x4 x = pm_philox4x32((uint32_t)(k0 + k), (uint32_t)r, PM_STREAM_BRANCH, 0u, seed);
+    int kp = k0 + k;                                      // particle index of the RNG contract
+    if (group_seeds) { const int g = kp / Kg; seed = group_seeds[g]; kp -= g * Kg; }
+    const pm_u32x4 x = pm_philox4x32((uint32_t)kp, (uint32_t)r, PM_STREAM_BRANCH, 0u, seed);
     const double b = side ? (-pm_log(pm_unit_oc(x.z, x.w))) / lam_r[r] : (-pm_log(pm_unit_oc(x.x, x.y))) / lam_l[r];
     (side ? br : bl)[i] = b;
     double q[16], p[16];
@@ -359,6 +362,17 @@ __global__ __launch_bounds__(PK_COLS) void pk_resample_scan(const double* logw, 
                                                          : reinterpret_cast<unsigned long long*>(cdf);
     pk_scan_block(logw, K, cdf, lse_out, sh, stage);
 }
+// G independent sweeps batched in one context: one workgroup per group scans its own K-segment
+__global__ __launch_bounds__(PK_COLS) void pk_resample_scan_groups(const double* logw, int K, uint64_t* __restrict__ cdf,
+                                                                    double* __restrict__ lse_out, int lse_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    pk_scan_lds* sh = reinterpret_cast<pk_scan_lds*>(smem);
+    const int g = blockIdx.x;
+    uint64_t* cg = cdf ? cdf + (size_t)g * K : nullptr;
+    unsigned long long* stage = (K <= PK_SCAN_LDS_MAX_K) ? reinterpret_cast<unsigned long long*>(smem + sizeof(pk_scan_lds))
+                                                         : reinterpret_cast<unsigned long long*>(cg);
+    pk_scan_block(logw + (size_t)g * K, K, cg, lse_out + (size_t)g * lse_stride, sh, stage);
+}
 __host__ inline size_t pk_scan_lds_bytes(int K) {
     return sizeof(pk_scan_lds) + (K <= PK_SCAN_LDS_MAX_K ? (size_t)K * 8 : 0);
 }
@@ -421,6 +435,15 @@ __global__ void pk_logz_total(const double* __restrict__ lse, int R, double* __r
     }
 }
 
+__global__ void pk_logz_total_groups(double* __restrict__ lse, int R, int stride) {     // lse[g][0..R-1] -> lse[g][R]
+    if (threadIdx.x == 0) {
+        double* l = lse + (size_t)blockIdx.x * stride;
+        double z = 0.0;
+        for (int r = 0; r < R; ++r) z = z + l[r];
+        l[R] = z;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // sweep state
 // ------------------------------------------------------------------------------------------------
@@ -475,6 +498,10 @@ struct pk_rank_args {
     // plane are read from its OWNER's table slab (peer mapping), byte offsets of that plane inside the slab
     const char* const* tab_ptrs;                          // [world] or NULL
     size_t tab_off_rootll, tab_off_roots, tab_off_cnt;
+    // G independent sweeps batched in one context (one GPU, plain proposal): particle kg belongs to group kg / Kg,
+    // draws with (kg % Kg, group_seeds[group]) and resamples inside its group's cdf segment.  Kg == K when unbatched.
+    int Kg;
+    const uint64_t* group_seeds;                          // [G] or NULL (use `seed`)
 };
 
 // LDS carve of the bookkeeping prologue (arrays of length N rounded up to a multiple of 4)
@@ -517,6 +544,10 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
     const int tid = threadIdx.x, lane = tid & 63;
     const bool w0 = tid < 64;
     const int n = a.n, N = a.N, k = kg - a.k0;
+    const int grp = a.group_seeds ? kg / a.Kg : 0;       // batched independent sweeps: my group, its seed, my index in it
+    const int gbase = grp * a.Kg;
+    const uint64_t seed = a.group_seeds ? a.group_seeds[grp] : a.seed;
+    const uint32_t kin = (uint32_t)(kg - gbase);
     if (w0) {
         // independent of the resampling outcome: issue first (slots >= 64 are copied further down)
         const double hb_l0 = (local && lane <= a.r) ? a.bl[(size_t)lane * a.Kloc + k] : 0.0;
@@ -524,12 +555,12 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
         const double ldf0 = (lane <= a.ldf_n) ? a.ldf[lane] : 0.0;
 #pragma unroll 1
         for (int b = lane; b < (n + 3) / 4; b += 64) {
-            const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_PAIR, (uint32_t)b, a.seed);
+            const pm_u32x4 x = pm_philox4x32(kin, (uint32_t)a.r, PM_STREAM_PAIR, (uint32_t)b, seed);
             L.key[b * 4 + 0] = x.x; L.key[b * 4 + 1] = x.y; L.key[b * 4 + 2] = x.z; L.key[b * 4 + 3] = x.w;
         }
         int anc = kg;
         if (a.r > 0) {
-            const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_RESAMPLE, 0u, a.seed);
+            const pm_u32x4 x = pm_philox4x32(kin, (uint32_t)a.r, PM_STREAM_RESAMPLE, 0u, seed);
             const uint64_t R = ((uint64_t)x.y << 32) | x.x;
             if (a.flag) {                             // the scan runs in workgroup 0 of this launch: wait for its flag
                 unsigned int spins = 0;
@@ -541,7 +572,7 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
                     }
                 }
             }
-            anc = pk_cdf_search_wave(a.cdf, a.K, R, lane, a.flag != nullptr);
+            anc = gbase + pk_cdf_search_wave(a.cdf + gbase, a.group_seeds ? a.Kg : a.K, R, lane, a.flag != nullptr);
         }
         const int32_t* ro = a.roots_old + (size_t)anc * N;
         const int32_t* co = a.cnt_old + (size_t)anc * N;
@@ -631,7 +662,7 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
             if (local) {
                 a.merges[((size_t)a.r * a.Kloc + k) * 2 + 0] = il;
                 a.merges[((size_t)a.r * a.Kloc + k) * 2 + 1] = ir;
-                if (a.r > 0) a.ancestors[(size_t)(a.r - 1) * a.Kloc + k] = L.misc[3];
+                if (a.r > 0) a.ancestors[(size_t)(a.r - 1) * a.Kloc + k] = L.misc[3] - gbase;   // index inside the group
             }
         }
     }

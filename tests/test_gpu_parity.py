@@ -439,3 +439,37 @@ def test_interleaved_contexts_are_deterministic(primate):
             assert ref.setdefault(seed, key) == key, "sweep with seed %d changed between repetitions" % seed
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("jc,G,Kg", [(True, 3, 32), (False, 4, 48)])
+def test_batched_independent_sweeps_equal_single_sweeps(primate, jc, G, Kg):
+    """phylo_sweep_batch_async: G sweeps in one set of launches; group g is bit for bit the sweep of Kg particles with
+    seeds[g] (own draws, own resampling segment, own log Z-hat)."""
+    g = primate
+    N = g.shape[0]
+    Q = O.jc_Q() if jc else O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    seeds = [11, 5, 902, 77][:G]
+    ctx = make_ctx(g, G * Kg, Q, jc=jc)
+    for rep in range(2):                                   # the second batch reuses every buffer
+        ctx.sweep_batch_async([s + rep for s in seeds])
+        out = ctx.sweep_fetch()
+        logz = ctx.sweep_fetch_logz(G)
+        for i, s in enumerate(seeds):
+            ref = CO.sweep(g, Q, PI, lam, lam, Kg, s + rep, jc=jc)
+            sl = slice(i * Kg, (i + 1) * Kg)
+            np.testing.assert_array_equal(out['ancestors'][:, sl], ref['ancestors'])
+            np.testing.assert_array_equal(out['merges'][:, sl], ref['merges'])
+            for key in ('log_weights', 'log_likelihood', 'left_branches', 'right_branches'):
+                assert_bit_equal(out[key][:, sl], ref[key], "%s of batched sweep %d" % (key, i))
+            assert logz[i] == ref['logZ']
+        assert out['logZ'] == logz[0]
+    # a plain sweep on the same context afterwards is the K-particle sweep again
+    a = ctx.sweep(3)
+    b = CO.sweep(g, Q, PI, lam, lam, G * Kg, 3, jc=jc)
+    assert_bit_equal(a['log_weights'], b['log_weights'], "plain sweep after a batch")
+    with pytest.raises(_ffi.PhyloError):
+        ctx.sweep_batch_async([1, 2, 3, 4, 5, 6, 7][:5] if (G * Kg) % 5 else [1] * 7)   # K not divisible by G
+    with pytest.raises(_ffi.PhyloError):
+        ctx.sweep_batch_async(seeds, flags=_ffi.FLAGS_DEFAULT | _ffi.TWISTING)
+    ctx.close()

@@ -26,10 +26,12 @@ def one(pattern):
 
 lines = ["# rocprofv3 summary, round %s" % tag, "",
          "Command: `python bench.py --steps 30 --warmup 3 --no-cpu-baseline` (primate.p N=12 S=898, GTR-init, K=2048;",
-         "default = 3 sweeps in flight; `--streams 1` = one sweep at a time; `twist` = `--twisting --M 1 --streams 1`;",
+         "default = 3 independent sweeps per set of launches (merge launches of 6144 particles) on 3 contexts in flight;",
+         "`1ctx` = `--streams 1`: the same launch sets one at a time -- the form whose merge launches `bench.py` times for `roofline`;",
+         "`1stream` = `--streams 1 --batch 1`, one sweep at a time (merge launches of 2048 particles); `twist` = `--twisting --M 1 --streams 1`;",
          "`ds1` = `--dataset hohna_data_1 --n_particles 4096 --streams 1`; `train` = `python tools/train_probe.py --steps 10`:",
          "VI training steps, sweep with the graph kept + reverse pass, pg_* kernels).  Raw tables: `%s_kernel_stats_*.csv`." % tag, ""]
-for name in ("default", "1stream", "twist", "ds1", "train"):
+for name in ("default", "1ctx", "1stream", "twist", "ds1", "train"):
     st = one("trace_%s/*/*_kernel_stats.csv" % name)
     if not st:
         continue
@@ -38,6 +40,15 @@ for name in ("default", "1stream", "twist", "ds1", "train"):
     for r in csv.DictReader(open(st)):
         lines.append("| %s | %s | %.2f | %.2f | %.2f | %s |" % (r['Name'][:60], r['Calls'], float(r['AverageNs']) / 1e3,
                                                          float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
+    tr = one("trace_%s/*/*_kernel_trace.csv" % name)
+    if tr:                                                 # the merge kernel by launch shape (bench.py also runs single sweeps)
+        shapes = collections.defaultdict(list)
+        for r in csv.DictReader(open(tr)):
+            if r['Kernel_Name'].startswith('pk_rank_merge'):
+                shapes[int(r['Grid_Size_X']) // 256].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        if len(shapes) > 0:
+            lines += ["", "`pk_rank_merge` by launch shape: " + "; ".join(
+                "%d particles: %d launches, avg %.2f us" % (k, len(v), sum(v) / len(v)) for k, v in sorted(shapes.items()))]
     log = open(os.path.join(src, "trace_%s.log" % name)).read()
     js = [l for l in log.splitlines() if l.startswith('{"metric"')]
     if js:
@@ -49,6 +60,14 @@ for name in ("default", "1stream", "twist", "ds1", "train"):
         lines += ["", "training step under the profiler: forward %.3f ms, reverse pass %.3f ms, step wall %.3f ms (K=%d, %d sites)"
                   % (j['forward_ms'], j['backward_ms'], j['step_wall_ms'], j['K'], j['sites']), ""]
 
+# particles per merge launch of the timed region of the profiled command (the bench also issues single sweeps)
+Kl = 2048
+try:
+    jl = [l for l in open(os.path.join(src, "pmc_fetch.log")).read().splitlines() if l.startswith('{"metric"')]
+    if jl:
+        Kl = int(round(json.loads(jl[-1])['roofline']['alg_bytes_per_launch'] / (96.0 * 898)))
+except Exception:
+    pass
 agg = {}
 for cn, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     f = one("%s/*/*_counter_collection.csv" % d)
@@ -57,7 +76,10 @@ for cn, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == cn:
-            per[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+            name = r['Kernel_Name'].split('(')[0]
+            if name == 'pk_rank_merge' and int(r['Grid_Size']) != Kl * 256:
+                continue                                   # a merge launch of another shape (the single-sweep section)
+            per[name].append(float(r['Counter_Value']))
     agg[cn] = {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
 if agg:
     lines += ["## HBM traffic from PMC counters (separate passes; values in KB per dispatch as rocprofv3 reports them)", "",
@@ -69,13 +91,13 @@ if agg:
     fz = agg.get("FETCH_SIZE", {}).get("pk_rank_merge", (0.0, 0))[0]
     wz = agg.get("WRITE_SIZE", {}).get("pk_rank_merge", (0.0, 0))[0]
     hbm = (2.0 * fz + wz) * 1024.0
-    alg = 96.0 * 2048 * 898
+    alg = 96.0 * Kl * 898
     lines += ["", "Merge kernel (`pk_rank_merge`), per launch: FETCH_SIZE %.0f KB is doubled (MI355X_MICROARCH.md, HBM: on gfx950" % fz,
               "FETCH_SIZE reports half the bytes of a 16 B/lane coalesced stream), WRITE_SIZE %.0f KB is exact for 16 B/lane" % wz,
-              "streaming stores: HBM traffic = 2 x FETCH + WRITE = **%.1f MB** against **%.1f MB** algorithmic (96 B x K x S)." % (hbm / 1e6, alg / 1e6),
+              "streaming stores: HBM traffic = 2 x FETCH + WRITE = **%.1f MB** against **%.1f MB** algorithmic (96 B x %d particles x S)." % (hbm / 1e6, alg / 1e6, Kl),
               "The children are leaves (L2-resident, 345 KB) or nodes of the few ancestors that survive resampling, so almost all",
-              "reads are served on chip; the kernel's HBM stream is the 59 MB it writes.", ""]
-    json.dump({"workload": "primate.p", "K": 2048, "kernel": "pk_rank_merge", "hbm_bytes_per_launch": hbm,
+              "reads are served on chip; the kernel's HBM stream is the store of the new nodes (32 B x particles x S = %.1f MB)." % (32.0 * Kl * 898 / 1e6), ""]
+    json.dump({"workload": "primate.p", "K": Kl, "kernel": "pk_rank_merge", "hbm_bytes_per_launch": hbm,
                "fetch_size_kb": fz, "write_size_kb": wz, "correction": "2*FETCH_SIZE + WRITE_SIZE (KB -> bytes x1024)",
                "round": tag}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
