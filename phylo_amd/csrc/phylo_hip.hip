@@ -33,6 +33,7 @@ struct sweep_run {                       // a sweep being issued rank event by r
     int M = 1, launches = 0, next_r = 0;
     bool twist = false, graph = false, lazy = false, timek = false, fuse_scan = false, active = false, local_book = false;
     int G = 1;                             // independent sweeps batched in this context (phylo_sweep_batch_async)
+    bool final_missing = false;            // the last rank event's nodes were not stored
 };
 
 struct phylo_ctx {
@@ -94,6 +95,7 @@ struct phylo_ctx {
     int32_t *d_heavy = nullptr, *d_chunk_beg = nullptr, *d_chunk_cnt = nullptr;   // [R K], [<= 2 R K / PG_PCHUNK + 1] x2
     bool graph_ready = false, last_graph = false;
     int last_G = 1;
+    bool last_final_missing = false;
     std::vector<uint64_t> h_group_seeds;
     hipEvent_t evb0 = nullptr, evb1 = nullptr;
     phylo_stats stats{};
@@ -729,6 +731,9 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
         b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
         b.seed = seed; b.flags = flags;
         b.Kg = Kg; b.group_seeds = G > 1 ? c->d_group_seeds : nullptr;
+        // the node of the LAST rank event is never merged again: its log-likelihood is all the sweep needs
+        b.no_store = (r == R - 1 && !graph && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES")) ? 1 : 0;
+        if (r == R - 1) c->run.final_missing = b.no_store && !lazy;
         if (graph) {                                       // every rank event keeps its tables: plane r -> plane r + 1
             b.roots_old = c->d_hroots + plane * r; b.cnt_old = c->d_hcnt + plane * r;
             b.roots_new = c->d_hroots + plane * (r + 1); b.cnt_new = c->d_hcnt + plane * (r + 1);
@@ -929,6 +934,7 @@ int phylo_sweep_finish(phylo_ctx* c) {
     c->last_lazy = lazy;
     c->last_graph = graph;
     c->last_G = c->run.G;
+    c->last_final_missing = c->run.final_missing;
     c->n_merge_events = timek ? R : 0;
     c->stats.n_launches = launches;
     c->stats.units = (double)Kl * S * R;
@@ -1041,6 +1047,15 @@ int phylo_sweep_node(phylo_ctx* c, int r, int k, double* out) {
             }
         }
         c->last_lazy = false;
+    }
+    if (c->last_final_missing && r == c->N - 2) {        // the sweep did not store the last rank event's nodes: write them now
+        pk_rank_args b{};
+        b.N = c->N; b.S = c->S; b.K = c->K; b.Kloc = c->Kloc; b.k0 = c->k0;
+        b.leaves = c->d_leaves; b.pool = c->d_pool; b.pool_ptrs = c->d_pool_ptrs;
+        b.child_all = c->d_child; b.Pmat_all = c->d_Pmat;
+        hipLaunchKernelGGL(pk_materialize_all, dim3(c->Kloc), dim3(PK_COLS), 0, c->stream, b, c->N - 2);
+        CHK(launch_check(c, "pk_materialize_all"));
+        c->last_final_missing = false;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const size_t node_sz = (size_t)c->S * 4;

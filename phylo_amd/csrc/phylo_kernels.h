@@ -502,6 +502,7 @@ struct pk_rank_args {
     // draws with (kg % Kg, group_seeds[group]) and resamples inside its group's cdf segment.  Kg == K when unbatched.
     int Kg;
     const uint64_t* group_seeds;                          // [G] or NULL (use `seed`)
+    int no_store;                                         // the merge does not store its node (last rank event: never read again)
 };
 
 // LDS carve of the bookkeeping prologue (arrays of length N rounded up to a multiple of 4)
@@ -741,6 +742,11 @@ __global__ __launch_bounds__(PK_COLS) void pk_materialize_rank(const pk_rank_arg
     if (threadIdx.x == 0) a.mark[(size_t)rho * a.K + a.k0 + k] = 1u;
 }
 
+// every node of rank event rho, unconditionally (the nodes of the last rank event are not stored by the sweep)
+__global__ __launch_bounds__(PK_COLS) void pk_materialize_all(const pk_rank_args a, int rho) {
+    pk_materialize_node(a, rho, a.k0 + blockIdx.x, threadIdx.x, PK_COLS, 0, a.S);
+}
+
 // Bookkeeping kernel: one 64-thread workgroup (one wave) per GLOBAL particle.  Particles of this rank's
 // shard also get their child node ids and weight terms written for the merge kernel; for the others only the
 // replicated integer state (root tables) is advanced.
@@ -962,7 +968,7 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a
         if (codedR) pk_merge_body<false, true, ST>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);  \
         else pk_merge_body<false, false, ST>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);        \
     }
-    if (a.lazy) { PK_MERGE_DISPATCH(false) } else { PK_MERGE_DISPATCH(true) }
+    if (a.lazy || a.no_store) { PK_MERGE_DISPATCH(false) } else { PK_MERGE_DISPATCH(true) }
 #undef PK_MERGE_DISPATCH
     cols[p + 128 * h] = pm_lp_finish(col);          // lane (p, h) owns canonical column p + 128 h
     __syncthreads();
