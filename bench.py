@@ -116,7 +116,7 @@ def main():
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     sharded_env = world > 1 or bool(os.environ.get('PHYLO_COMM_FORCE_RCCL'))
-    # batching keeps every node (no lazy nodes): it pays where launches are short, i.e. below the lazy-node threshold
+    # batching pays where launches are short (small nodes); large nodes fill the GPU with one sweep per launch set
     batch = a.batch if a.batch > 0 else (3 if not (sharded_env or a.twisting) and S < 8192 else 1)
     if batch > 1 and (sharded_env or a.twisting):
         raise SystemExit("--batch needs one GPU and the plain proposal")
@@ -175,6 +175,7 @@ def main():
         for c in ctxs:
             c.synchronize()
 
+    run(n_streams * batch, a.seed + 2000)            # untimed: every context (and its pool's pages) touched once
     run(max(a.warmup, 0), a.seed + 1000)
     ctx.comm_barrier()
     t0 = time.perf_counter()

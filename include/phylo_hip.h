@@ -47,9 +47,10 @@ enum {
                                           Set = as the reference.  */
     PHYLO_TWISTING = 1u << 1,          /* twisted/nested proposal of vncsmc.py:295-416 (uses M)          */
     PHYLO_TIME_KERNELS = 1u << 2,      /* bracket every merge launch with HIP events (profiling runs)    */
-    PHYLO_EAGER_NODES = 1u << 3,       /* always store every new node's partial likelihoods.  Default: on one GPU, plain
-                                          proposal, S >= 8192, only nodes whose creator survives the next resampling
-                                          are written (the rest are dead stores); results are identical either way.
+    PHYLO_EAGER_NODES = 1u << 3,       /* always store every new node's partial likelihoods.  Default with the plain
+                                          proposal (one GPU: always; sharded: S >= 8192): only nodes whose creator
+                                          survives the next resampling are written (the rest are dead stores);
+                                          results are identical either way.
                                           The nodes of the LAST rank event are never read by a merge and are not stored
                                           either (phylo_sweep_node writes them on demand) unless this flag is set */
     PHYLO_KEEP_GRAPH = 1u << 4,        /* keep what phylo_sweep_backward needs (root-table history of every rank

@@ -680,7 +680,10 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
         CHK(ensure_graph_state(c));
     }
     const bool lazy_ok = !twist && !graph && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES");
-    const bool lazy = lazy_ok && ((G == 1 && S >= 8192) || getenv("PHYLO_LAZY_NODES"));
+    // one GPU: always (marks are plain stores, the extra launch costs less than the dead stores it removes at every
+    // size measured); sharded: only where nodes are large, because the owner's write needs one more collective per
+    // rank event and the bookkeeping of all K particles on every rank
+    const bool lazy = lazy_ok && (c->world == 1 || S >= 8192 || getenv("PHYLO_LAZY_NODES"));
     int launches = 0;
     const bool fuse_scan = !twist && !graph && G == 1 && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
     c->swept = false;

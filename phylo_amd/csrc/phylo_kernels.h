@@ -727,8 +727,8 @@ __device__ __forceinline__ void pk_materialize_node(const pk_rank_args& a, int r
 // not limited to one CU's bandwidth.
 #define PK_MAT_TILE 1024
 __global__ __launch_bounds__(PK_COLS) void pk_materialize_adopted(const pk_rank_args a) {
-    if (blockIdx.y >= *a.mat_count) return;
-    const int node = a.mat_list[blockIdx.y];
+    const int node = a.k0 + blockIdx.y;                // grid (site tiles, local particles): unmarked nodes leave at once
+    if (!a.mark[(size_t)(a.r - 1) * a.K + node]) return;
     const int s0 = blockIdx.x * PK_MAT_TILE, s1 = s0 + PK_MAT_TILE < a.S ? s0 + PK_MAT_TILE : a.S;
     pk_materialize_node(a, a.r - 1, node, threadIdx.x, PK_COLS, s0, s1);
 }
@@ -762,11 +762,10 @@ __global__ __launch_bounds__(64) void pk_rank_book(const pk_rank_args a) {
         else a.child[k * 2 + (threadIdx.x - PK_AUX)] = L.misc[threadIdx.x - PK_AUX];
     }
     if (a.lazy && a.r > 0 && threadIdx.x == 0) {
-        // this particle adopted the table of `anc`: the node anc created at the previous rank event is now live.
-        // The first adopter queues it for pk_materialize_adopted.
+        // this particle adopted the table of `anc`: the node anc created at the previous rank event is now live;
+        // pk_materialize_adopted writes the marked nodes of that rank event.
         const int anc = L.misc[3];                    // every rank sees every adoption; the OWNER of the node writes it
-        if (atomicExch(a.mark + (size_t)(a.r - 1) * a.K + anc, 1u) == 0u && anc >= a.k0 && anc < a.k0 + a.Kloc)
-            a.mat_list[atomicAdd(a.mat_count, 1u)] = anc;
+        a.mark[(size_t)(a.r - 1) * a.K + anc] = 1u;  // plain store: every adopter writes the same value (no contended atomics)
     }
 }
 
@@ -800,11 +799,10 @@ __global__ __launch_bounds__(PK_COLS) void pk_rank_scan_book(const pk_rank_args 
         else a.child[k * 2 + (threadIdx.x - PK_AUX)] = L.misc[threadIdx.x - PK_AUX];
     }
     if (a.lazy && a.r > 0 && threadIdx.x == 0) {
-        // this particle adopted the table of `anc`: the node anc created at the previous rank event is now live.
-        // The first adopter queues it for pk_materialize_adopted.
+        // this particle adopted the table of `anc`: the node anc created at the previous rank event is now live;
+        // pk_materialize_adopted writes the marked nodes of that rank event.
         const int anc = L.misc[3];                    // every rank sees every adoption; the OWNER of the node writes it
-        if (atomicExch(a.mark + (size_t)(a.r - 1) * a.K + anc, 1u) == 0u && anc >= a.k0 && anc < a.k0 + a.Kloc)
-            a.mat_list[atomicAdd(a.mat_count, 1u)] = anc;
+        a.mark[(size_t)(a.r - 1) * a.K + anc] = 1u;  // plain store: every adopter writes the same value (no contended atomics)
     }
 }
 
