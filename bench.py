@@ -193,6 +193,9 @@ def main():
 
     # one sweep at a time on one stream (latency of a single sweep), and the dominant kernel (the
     # Felsenstein merge): average launch duration from HIP events on the ctx stream, nothing else in flight
+    for s in range(3):                              # untimed: this context's pages and caches
+        single.sweep_async(a.seed + 3000 + s, flags=sweep_flags, M=a.M)
+    single.synchronize()
     t1 = time.perf_counter()
     for s in range(10):
         single.sweep_async(a.seed + s, flags=sweep_flags, M=a.M)

@@ -96,7 +96,10 @@ if agg:
               "FETCH_SIZE reports half the bytes of a 16 B/lane coalesced stream), WRITE_SIZE %.0f KB is exact for 16 B/lane" % wz,
               "streaming stores: HBM traffic = 2 x FETCH + WRITE = **%.1f MB** against **%.1f MB** algorithmic (96 B x %d particles x S)." % (hbm / 1e6, alg / 1e6, Kl),
               "The children are leaves (L2-resident, 345 KB) or nodes of the few ancestors that survive resampling, so almost all",
-              "reads are served on chip; the kernel's HBM stream is the store of the new nodes (32 B x particles x S = %.1f MB)." % (32.0 * Kl * 898 / 1e6), ""]
+              "reads are served on chip." + (" The launch stores no nodes (lazy nodes, the default on one GPU): only the nodes whose creator"
+              " is adopted at the next resampling are written, by `pk_materialize_adopted` (its line above); the %.1f MB of"
+              " node stores per launch of the eager form are gone." % (32.0 * Kl * 898 / 1e6) if wz * 1024 < 0.1 * 32.0 * Kl * 898 else
+              " The kernel's HBM stream is the store of the new nodes (32 B x particles x S = %.1f MB)." % (32.0 * Kl * 898 / 1e6)), ""]
     json.dump({"workload": "primate.p", "K": Kl, "kernel": "pk_rank_merge", "hbm_bytes_per_launch": hbm,
                "fetch_size_kb": fz, "write_size_kb": wz, "correction": "2*FETCH_SIZE + WRITE_SIZE (KB -> bytes x1024)",
                "round": tag}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
