@@ -830,10 +830,15 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                 CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
             }
         }
-        if (timek)   // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
-            hipExtLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
-        else
+        const bool nostore = (b.lazy || b.no_store) && !getenv("PHYLO_MERGE_PAIR_FORM");   // row-per-thread form when nothing is stored
+        if (timek) {  // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
+            if (nostore) hipExtLaunchKernelGGL(pk_rank_merge_nostore, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
+            else hipExtLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
+        } else if (nostore) {
+            hipLaunchKernelGGL(pk_rank_merge_nostore, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
+        } else {
             hipLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
+        }
         CHK(launch_check(c, "pk_rank_merge"));
         ++launches;
     }

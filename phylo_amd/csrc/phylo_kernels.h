@@ -931,6 +931,18 @@ __device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, const doubl
     }
 }
 
+// log_likelihood_r and log w_r of the particle from the new node's log-likelihood and the bookkeeping terms (k8)
+__device__ __forceinline__ void pk_merge_epilogue(const pk_rank_args& a, int k, int kg, double tot) {
+    const double* ax = a.aux + (size_t)k * PK_AUX;
+    const double fl = ax[AUX_SUM_REM] + tot;
+    const double ll = ((fl + ax[AUX_FPRIOR]) + ax[AUX_LPRIOR]) + ax[AUX_RPRIOR];
+    const double lw = (((ll - ax[AUX_LL_TILDE]) - ax[AUX_PAREN]) + ax[AUX_LOGV]) - ax[AUX_Q];
+    a.nodell[a.N + a.r * a.K + kg] = tot;
+    a.rootll_new[(size_t)kg * a.N + (a.n - 2)] = tot;
+    a.ll_r[kg] = ll;
+    a.logw_r[kg] = lw;
+}
+
 __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a) {
     __shared__ double cols[PK_COLS];
     __shared__ double sh4[4];
@@ -971,16 +983,7 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a
     cols[p + 128 * h] = pm_lp_finish(col);          // lane (p, h) owns canonical column p + 128 h
     __syncthreads();
     const double tot = pk_block_canon_sum(cols[tid], sh4);
-    if (tid == 0) {
-        const double* ax = a.aux + (size_t)k * PK_AUX;
-        const double fl = ax[AUX_SUM_REM] + tot;
-        const double ll = ((fl + ax[AUX_FPRIOR]) + ax[AUX_LPRIOR]) + ax[AUX_RPRIOR];
-        const double lw = (((ll - ax[AUX_LL_TILDE]) - ax[AUX_PAREN]) + ax[AUX_LOGV]) - ax[AUX_Q];
-        a.nodell[a.N + a.r * a.K + kg] = tot;
-        a.rootll_new[(size_t)kg * a.N + (a.n - 2)] = tot;
-        a.ll_r[kg] = ll;
-        a.logw_r[kg] = lw;
-    }
+    if (tid == 0) pk_merge_epilogue(a, k, kg, tot);
 }
 
 // multi-GPU: after the all-gather of node log-likelihoods, complete the root tables of the other ranks'
@@ -1137,6 +1140,45 @@ __device__ __forceinline__ double pk_uniform(double v) {
     hi = __builtin_amdgcn_readfirstlane(hi);
     return __hiloint2double(hi, lo);
 }
+// The merge of one rank event when the new node is NOT stored (lazy nodes, the last rank event): only the node's
+// log-likelihood is needed, so the row-per-thread form applies -- thread c owns canonical column c (sites c, c+256,
+// ...), reads whole 32-byte rows (or 1-byte codes), and needs no DPP moves: about half the instructions per site of
+// the lane-pair form, whose point is the 16-byte-per-lane store.  Same fma chains, same column products: same bits.
+__global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_rank_args a) {
+    __shared__ double cols[PK_COLS];
+    __shared__ double sh4[4];
+    __shared__ __attribute__((aligned(16))) double tabL[5][4], tabR[5][4];
+    const int k = blockIdx.x, kg = a.k0 + k, tid = threadIdx.x;
+    const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
+    const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // workgroup-uniform
+    const double* Lp = pk_node_ptr(a, cl);
+    const double* Rp = pk_node_ptr(a, cr);
+    const uint8_t* Lc = a.leaf_codes + (codedL ? (size_t)cl * a.S : 0);
+    const uint8_t* Rc = a.leaf_codes + (codedR ? (size_t)cr * a.S : 0);
+    const double* Pu = a.Pmat + (size_t)k * 32;
+    double Pl[16], Pr[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { Pl[u] = pk_uniform(Pu[u]); Pr[u] = Pu[16 + u]; }   // P_l in SGPRs, P_r in VGPRs (both would spill)
+    if (codedL || codedR) {
+        if (tid < 32) pk_build_leaf_table(Pu, tabL, tid);
+        else if (tid < 64) pk_build_leaf_table(Pu + 16, tabR, tid - 32);
+        __syncthreads();
+    }
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    pm_lp col = pm_lp_init();
+    if (codedL) {
+        if (codedR) pk_twist_row<true, true>(a, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col);
+        else pk_twist_row<true, false>(a, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col);
+    } else {
+        if (codedR) pk_twist_row<false, true>(a, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col);
+        else pk_twist_row<false, false>(a, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col);
+    }
+    cols[tid] = pm_lp_finish(col);
+    __syncthreads();
+    const double tot = pk_block_canon_sum(cols[tid], sh4);
+    if (tid == 0) pk_merge_epilogue(a, k, kg, tot);
+}
+
 #define PK_TWIST_LDS_ROWS 8              // (pair, sub-sample) rows staged and reduced per pass
 #define PK_TWIST_MAX_ROWS 512            // (N-1) M of one workgroup; C(N,2) M <= PK_TWIST_MAX_J and M <= 16 keep it below 360
 
