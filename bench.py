@@ -212,6 +212,10 @@ def main():
         merge_ms += st['merge_ms']
         merge_n += st['merge_launches']
     bytes_per_launch = 96.0 * ctx.K_local * S       # 2 child reads + 1 parent write, 32 B each, per (particle, site)
+    # lazy nodes (one GPU, plain proposal, or large nodes when sharded): the launch stores nothing and runs the
+    # row-per-thread form of the merge
+    lazy_nodes = not a.twisting and not os.environ.get('PHYLO_EAGER_NODES') and (not sharded or S >= 8192)
+    merge_kernel = "pk_rank_merge_nostore" if lazy_nodes else "pk_rank_merge"
     avg_s = merge_ms / merge_n * 1e-3
     achieved = bytes_per_launch / avg_s / 1e9
     traffic = None
@@ -219,7 +223,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get('workload') == wname and tj.get('K') == ctx.K_local:
+            if tj.get('workload') == wname and tj.get('K') == ctx.K_local and tj.get('kernel') == merge_kernel:
                 traffic = tj.get('hbm_bytes_per_launch')
         except Exception:
             traffic = None
@@ -241,7 +245,7 @@ def main():
                        "sweeps_in_flight": n_streams * batch},
             "single_sweep_ms": single_ms,
             "log_Z": last['logZ'],
-            "roofline": {"bound": "hbm", "kernel": "pk_rank_merge", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": merge_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "alg_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6,
                          "sweep_frac_of_peak": (96.0 * units_per_step / world) / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS},

@@ -77,7 +77,7 @@ for cn, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == cn:
             name = r['Kernel_Name'].split('(')[0]
-            if name == 'pk_rank_merge' and int(r['Grid_Size']) != Kl * 256:
+            if name.startswith('pk_rank_merge') and int(r['Grid_Size']) != Kl * 256:
                 continue                                   # a merge launch of another shape (the single-sweep section)
             per[name].append(float(r['Counter_Value']))
     agg[cn] = {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
@@ -88,11 +88,14 @@ if agg:
         fz = agg.get("FETCH_SIZE", {}).get(k, (0.0, 0))
         wz = agg.get("WRITE_SIZE", {}).get(k, (0.0, 0))
         lines.append("| %s | %.1f | %.1f | %d |" % (k, fz[0], wz[0], max(fz[1], wz[1])))
-    fz = agg.get("FETCH_SIZE", {}).get("pk_rank_merge", (0.0, 0))[0]
-    wz = agg.get("WRITE_SIZE", {}).get("pk_rank_merge", (0.0, 0))[0]
+    # the merge kernel of the timed region: the row-per-thread form when nothing is stored (lazy nodes), else the pair form
+    mk = "pk_rank_merge_nostore" if agg.get("FETCH_SIZE", {}).get("pk_rank_merge_nostore", (0.0, 0))[1] >= \
+        agg.get("FETCH_SIZE", {}).get("pk_rank_merge", (0.0, 0))[1] else "pk_rank_merge"
+    fz = agg.get("FETCH_SIZE", {}).get(mk, (0.0, 0))[0]
+    wz = agg.get("WRITE_SIZE", {}).get(mk, (0.0, 0))[0]
     hbm = (2.0 * fz + wz) * 1024.0
     alg = 96.0 * Kl * 898
-    lines += ["", "Merge kernel (`pk_rank_merge`), per launch: FETCH_SIZE %.0f KB is doubled (MI355X_MICROARCH.md, HBM: on gfx950" % fz,
+    lines += ["", "Merge kernel (`%s`), per launch:" % mk + " FETCH_SIZE %.0f KB is doubled (MI355X_MICROARCH.md, HBM: on gfx950" % fz,
               "FETCH_SIZE reports half the bytes of a 16 B/lane coalesced stream), WRITE_SIZE %.0f KB is exact for 16 B/lane" % wz,
               "streaming stores: HBM traffic = 2 x FETCH + WRITE = **%.1f MB** against **%.1f MB** algorithmic (96 B x %d particles x S)." % (hbm / 1e6, alg / 1e6, Kl),
               "The children are leaves (L2-resident, 345 KB) or nodes of the few ancestors that survive resampling, so almost all",
@@ -100,7 +103,7 @@ if agg:
               " is adopted at the next resampling are written, by `pk_materialize_adopted` (its line above); the %.1f MB of"
               " node stores per launch of the eager form are gone." % (32.0 * Kl * 898 / 1e6) if wz * 1024 < 0.1 * 32.0 * Kl * 898 else
               " The kernel's HBM stream is the store of the new nodes (32 B x particles x S = %.1f MB)." % (32.0 * Kl * 898 / 1e6)), ""]
-    json.dump({"workload": "primate.p", "K": Kl, "kernel": "pk_rank_merge", "hbm_bytes_per_launch": hbm,
+    json.dump({"workload": "primate.p", "K": Kl, "kernel": mk, "hbm_bytes_per_launch": hbm,
                "fetch_size_kb": fz, "write_size_kb": wz, "correction": "2*FETCH_SIZE + WRITE_SIZE (KB -> bytes x1024)",
                "round": tag}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
