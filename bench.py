@@ -117,9 +117,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     sharded_env = world > 1 or bool(os.environ.get('PHYLO_COMM_FORCE_RCCL'))
     # batching pays where launches are short (small nodes); large nodes fill the GPU with one sweep per launch set
-    batch = a.batch if a.batch > 0 else (3 if not (sharded_env or a.twisting) and S < 8192 else 1)
-    if batch > 1 and (sharded_env or a.twisting):
-        raise SystemExit("--batch needs one GPU and the plain proposal")
+    batch = a.batch if a.batch > 0 else (3 if not a.twisting and S < 8192 else 1)
+    if batch > 1 and a.twisting:
+        raise SystemExit("--batch needs the plain proposal")
     n_streams = a.streams if a.streams > 0 else 3
     pool_bytes = 32.0 * (N - 1) * a.n_particles * batch * S   # node pool of one context
     while n_streams > 1 and n_streams * pool_bytes > 200e9:
@@ -144,34 +144,41 @@ def main():
         single = _ffi.Context(K_global, N, S, device=local_rank % ndev)
         single.set_leaves(g)
         single.set_model(Q, pi, lam, lam, jc69_closed_form=a.jcmodel)
+        if sharded:
+            single.comm_share(ctx)
 
     def run(n, seed0):
-        if batch > 1:
-            # `batch` independent sweeps per set of launches, contexts round-robin; a remainder runs as single sweeps
-            nb = n // batch
-            for i in range(nb):
-                ctxs[i % n_streams].sweep_batch_async([seed0 + i * batch + j for j in range(batch)], flags=sweep_flags)
-            for j in range(n - nb * batch):
-                single.sweep_async(seed0 + nb * batch + j, flags=sweep_flags, M=a.M)
-            single.synchronize()
-        elif not sharded or n_streams == 1:
-            for s in range(n):
-                ctxs[s % n_streams].sweep_async(seed0 + s, flags=sweep_flags, M=a.M)
-        else:
-            # sharded: the sweeps in flight advance rank event by rank event, so every rank issues the collectives of
-            # the shared communicator in the same order, fused into one grouped all-gather per rank event
-            for s0 in range(0, n, n_streams):
-                group = ctxs[:min(n_streams, n - s0)]
+        nb = n // batch
+        if sharded:
+            # the contexts in flight advance rank event by rank event, so every rank issues the collectives of the shared
+            # communicator in the same order, fused into one grouped all-gather per rank event; each context carries
+            # `batch` independent sweeps (its K = batch * K_global particle indices sharded by contiguous ranges)
+            for i0 in range(0, nb, n_streams):
+                group = ctxs[:min(n_streams, nb - i0)]
                 for i, c in enumerate(group):
-                    c.sweep_begin(seed0 + s0 + i, flags=sweep_flags, M=a.M)
+                    if batch > 1:
+                        c.sweep_batch_begin([seed0 + (i0 + i) * batch + j for j in range(batch)], flags=sweep_flags)
+                    else:
+                        c.sweep_begin(seed0 + i0 + i, flags=sweep_flags, M=a.M)
                 for _ in range(N - 1):
                     if os.environ.get('PHYLO_BENCH_UNGROUPED'):
-                        for c in group:                   # one collective per sweep and rank event
+                        for c in group:                   # one collective per context and rank event
                             c.sweep_step()
-                    else:                                 # one grouped all-gather per rank event for the whole group
+                    else:
                         _ffi.sweep_step_group(group)
                 for c in group:
                     c.sweep_finish()
+        elif batch > 1:
+            # `batch` independent sweeps per set of launches, contexts round-robin
+            for i in range(nb):
+                ctxs[i % n_streams].sweep_batch_async([seed0 + i * batch + j for j in range(batch)], flags=sweep_flags)
+        else:
+            for s in range(n):
+                ctxs[s % n_streams].sweep_async(seed0 + s, flags=sweep_flags, M=a.M)
+        if batch > 1:                                     # a remainder runs as single sweeps
+            for j in range(n - nb * batch):
+                single.sweep_async(seed0 + nb * batch + j, flags=sweep_flags, M=a.M)
+            single.synchronize()
         for c in ctxs:
             c.synchronize()
 
@@ -214,7 +221,7 @@ def main():
     bytes_per_launch = 96.0 * ctx.K_local * S       # 2 child reads + 1 parent write, 32 B each, per (particle, site)
     # lazy nodes (one GPU, plain proposal, or large nodes when sharded): the launch stores nothing and runs the
     # row-per-thread form of the merge
-    lazy_nodes = not a.twisting and not os.environ.get('PHYLO_EAGER_NODES') and (not sharded or S >= 8192)
+    lazy_nodes = not a.twisting and not os.environ.get('PHYLO_EAGER_NODES') and (world == 1 or S >= 8192)
     merge_kernel = "pk_rank_merge_nostore" if lazy_nodes else "pk_rank_merge"
     avg_s = merge_ms / merge_n * 1e-3
     achieved = bytes_per_launch / avg_s / 1e9

@@ -144,8 +144,11 @@ int phylo_synchronize(phylo_ctx* ctx);
  * replicates): the context's K particles are G groups of K/G; group g is exactly the sweep of K/G particles with
  * seeds[g] (own draws, own resampling, own log Z-hat).  Outputs of phylo_sweep_fetch hold group g in columns
  * [g K/G, (g+1) K/G) (ancestors index inside the group); phylo_sweep_fetch_logz returns the G estimates.
- * One GPU, plain proposal, eager nodes. */
+ * Plain proposal.  Sharded contexts too: the K = G * (K/G) particle indices are sharded by contiguous ranges as
+ * always (a group may straddle ranks), one all-gather per rank event carries all G sweeps.
+ * phylo_sweep_batch_begin + phylo_sweep_step(_group) + phylo_sweep_finish is the stepwise form. */
 int phylo_sweep_batch_async(phylo_ctx* ctx, const uint64_t* seeds, int G, uint32_t flags);
+int phylo_sweep_batch_begin(phylo_ctx* ctx, const uint64_t* seeds, int G, uint32_t flags);
 int phylo_sweep_fetch_logz(phylo_ctx* ctx, double* logZ_G, int G);
 
 /* The same sweep issued one rank event at a time: begin (draws, tables), N-1 x step, finish (log Z-hat).

@@ -625,8 +625,8 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     c->run.active = false;
     if (G < 1 || G > PK_MAX_GROUPS || c->K % G != 0)
         return fail(c, PHYLO_EINVAL, "a batch needs 1 <= G <= %d sweeps and K = %d divisible by G (got %d)", PK_MAX_GROUPS, c->K, G);
-    if (G > 1 && (c->world != 1 || (flags & (PHYLO_TWISTING | PHYLO_KEEP_GRAPH))))
-        return fail(c, PHYLO_EINVAL, "batched sweeps need one GPU and the plain proposal without PHYLO_KEEP_GRAPH");
+    if (G > 1 && (flags & (PHYLO_TWISTING | PHYLO_KEEP_GRAPH)))
+        return fail(c, PHYLO_EINVAL, "batched sweeps need the plain proposal without PHYLO_KEEP_GRAPH");
     if (!c->have_leaves || !c->have_model)
         return fail(c, PHYLO_ESTATE, "phylo_set_leaves and phylo_set_model must be called before a sweep");
     if (!c->state_ready) {
@@ -961,11 +961,15 @@ int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
     return phylo_sweep_finish(c);
 }
 
-int phylo_sweep_batch_async(phylo_ctx* c, const uint64_t* seeds, int G, uint32_t flags) {
+int phylo_sweep_batch_begin(phylo_ctx* c, const uint64_t* seeds, int G, uint32_t flags) {
     if (!c) return fail(nullptr, PHYLO_EINVAL, "ctx is NULL");
     if (!seeds) return fail(c, PHYLO_EINVAL, "seeds is NULL");
     c->h_group_seeds.assign(seeds, seeds + (G > 0 ? G : 0));          // stays alive until the copy has run
-    CHK(sweep_begin_impl(c, G > 0 ? seeds[0] : 0, flags, 1, c->h_group_seeds.data(), G));
+    return sweep_begin_impl(c, G > 0 ? seeds[0] : 0, flags, 1, c->h_group_seeds.data(), G);
+}
+
+int phylo_sweep_batch_async(phylo_ctx* c, const uint64_t* seeds, int G, uint32_t flags) {
+    CHK(phylo_sweep_batch_begin(c, seeds, G, flags));
     for (int r = 0; r < c->N - 1; ++r) CHK(phylo_sweep_step(c));
     return phylo_sweep_finish(c);
 }

@@ -29,6 +29,17 @@ def main():
     res = None
     twist_M = int(os.environ.get('PHYLO_TEST_TWIST_M', '0'))
     flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if twist_M else 0)
+    batch = int(os.environ.get('PHYLO_TEST_BATCH', '0'))
+    if batch:                                      # G independent sweeps in one sharded context (bench.py at N > 1)
+        seeds = [seed + 10 * i for i in range(batch)]
+        for rep in range(n_sweeps):
+            ctx.sweep_batch_async(seeds, flags=flags)
+        res = ctx.sweep_fetch()
+        logz = ctx.sweep_fetch_logz(batch)
+        np.savez(out, log_weights=res['log_weights'], log_likelihood=res['log_likelihood'], ancestors=res['ancestors'],
+                 merges=res['merges'], logz=logz, k0=ctx.k0)
+        ctx.close()
+        return
     inflight = int(os.environ.get('PHYLO_TEST_INFLIGHT', '1'))
     others = []
     if inflight > 1:

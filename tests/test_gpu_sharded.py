@@ -144,6 +144,29 @@ def test_sweeps_in_flight_share_one_communicator(transport, world, extra):
         assert np.array_equal(p['node'].view(np.uint64), ref_last['nodes'][N - 2, (r + 1) * Kl - 1].view(np.uint64))
 
 
+@pytest.mark.parametrize("world,G,Kg", [(2, 3, 32), (3, 2, 48)])
+def test_batched_sweeps_on_sharded_contexts(world, G, Kg):
+    """G independent sweeps in ONE sharded context: the G * Kg particle indices are sharded by contiguous ranges (a
+    group straddles ranks when world does not divide G), one all-gather per rank event carries all of them, and
+    every group is bit for bit the Kg-particle sweep of its seed."""
+    seed = 6
+    parts = run_world(world, G * Kg, 'primate_data', seed, False, n_sweeps=2, extra_env={'PHYLO_TEST_BATCH': str(G)})
+    g = load_dataset('primate_data')['genome']
+    N = g.shape[0]
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    refs = [CO.sweep(g, Q, PI, lam, lam, Kg, seed + 10 * i) for i in range(G)]
+    flat = {k: np.concatenate([r[k] for r in refs], axis=1) for k in ('log_weights', 'log_likelihood', 'ancestors', 'merges')}
+    Kl = G * Kg // world
+    for r, p in enumerate(parts):
+        sl = slice(r * Kl, (r + 1) * Kl)
+        np.testing.assert_array_equal(p['ancestors'], flat['ancestors'][:, sl])       # indices inside the group
+        np.testing.assert_array_equal(p['merges'], flat['merges'][:, sl])
+        assert np.array_equal(p['log_weights'].view(np.uint64), flat['log_weights'][:, sl].view(np.uint64))
+        assert np.array_equal(p['log_likelihood'].view(np.uint64), flat['log_likelihood'][:, sl].view(np.uint64))
+        assert list(p['logz']) == [ref['logZ'] for ref in refs]                        # every rank holds every estimate
+
+
 def test_stepwise_sweep_equals_whole_sweep():
     """phylo_sweep_begin / step / finish, interleaved over two unsharded contexts, against phylo_sweep."""
     g = load_dataset('primate_data_wang')['genome']
