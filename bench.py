@@ -117,10 +117,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     sharded_env = world > 1 or bool(os.environ.get('PHYLO_COMM_FORCE_RCCL'))
     # batching pays where launches are short (small nodes); large nodes fill the GPU with one sweep per launch set
-    batch = a.batch if a.batch > 0 else (3 if not a.twisting and S < 8192 else 1)
+    batch = a.batch if a.batch > 0 else ((6 if sharded_env else 3) if not a.twisting and S < 8192 else 1)
     if batch > 1 and a.twisting:
         raise SystemExit("--batch needs the plain proposal")
-    n_streams = a.streams if a.streams > 0 else 3
+    n_streams = a.streams if a.streams > 0 else (2 if sharded_env and batch > 1 else 3)
     pool_bytes = 32.0 * (N - 1) * a.n_particles * batch * S   # node pool of one context
     while n_streams > 1 and n_streams * pool_bytes > 200e9:
         n_streams -= 1                                # every sweep in flight owns a pool; stay inside 288 GB of HBM
@@ -151,8 +151,10 @@ def main():
         nb = n // batch
         if sharded:
             # the contexts in flight advance rank event by rank event, so every rank issues the collectives of the shared
-            # communicator in the same order, fused into one grouped all-gather per rank event; each context carries
-            # `batch` independent sweeps (its K = batch * K_global particle indices sharded by contiguous ranges)
+            # communicator in the same order; each context carries `batch` independent sweeps (its K = batch * K_global
+            # particle indices sharded by contiguous ranges).  One collective per context and rank event lets the
+            # contexts drift out of phase, so one computes while the other waits for its all-gather (measured better
+            # than one grouped collective for all contexts, PHYLO_BENCH_GROUPED=1, which stalls every context at once)
             for i0 in range(0, nb, n_streams):
                 group = ctxs[:min(n_streams, nb - i0)]
                 for i, c in enumerate(group):
@@ -161,11 +163,11 @@ def main():
                     else:
                         c.sweep_begin(seed0 + i0 + i, flags=sweep_flags, M=a.M)
                 for _ in range(N - 1):
-                    if os.environ.get('PHYLO_BENCH_UNGROUPED'):
-                        for c in group:                   # one collective per context and rank event
-                            c.sweep_step()
-                    else:
+                    if os.environ.get('PHYLO_BENCH_GROUPED'):
                         _ffi.sweep_step_group(group)
+                    else:
+                        for c in group:
+                            c.sweep_step()
                 for c in group:
                     c.sweep_finish()
         elif batch > 1:
