@@ -73,8 +73,6 @@ struct phylo_ctx {
     int32_t* d_child = nullptr;          // [(N-1)][Kloc][2]: children of every node (kept for lazy materialisation)
     unsigned int* d_mark = nullptr;      // [(N-1)][K]: node is in the pool
     double* d_sync = nullptr;  // [world] dummy payload of the barrier collective used by lazy nodes when sharded
-    int32_t* d_mat_list = nullptr;       // [K] nodes queued for materialisation at the current rank event
-    unsigned int* d_mat_count = nullptr; // [(N-1)] one counter per rank event (zeroed with the marks)
     bool last_lazy = false;
     int32_t* d_merges = nullptr;         // [(N-1)][Kloc][2]
     int64_t* d_anc = nullptr;            // [(N-2)][Kloc]
@@ -196,7 +194,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->last_graph = false;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse, c->d_group_seeds,
                     c->d_tables, (void*)c->d_tab_ptrs, c->d_child, c->d_merges, c->d_anc,
-                    c->d_cdf[0], c->d_cdf[1], c->d_counter, (void*)c->d_pool_ptrs, c->d_mark, c->d_mat_list, c->d_sync};
+                    c->d_cdf[0], c->d_cdf[1], c->d_counter, (void*)c->d_pool_ptrs, c->d_mark, c->d_sync};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_pool = c->d_nodell = c->d_bl = c->d_br = c->d_Pmat = c->d_logw = c->d_ll = c->d_aux = c->d_lse = nullptr;
@@ -210,9 +208,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_tab_ptrs = nullptr;
     c->d_pool_ptrs = nullptr;
     c->d_mark = nullptr;
-    c->d_mat_list = nullptr;
     c->d_sync = nullptr;
-    c->d_mat_count = nullptr;
 }
 
 int alloc_sweep_state(phylo_ctx* c) {
@@ -236,9 +232,7 @@ int alloc_sweep_state(phylo_ctx* c) {
         c->d_cnt[i] = reinterpret_cast<int32_t*>(c->d_tables + 24 * K * N) + (size_t)i * K * N;
     }
     CHK(dalloc(c, &c->d_child, R * Kl * 2));
-    CHK(dalloc(c, &c->d_mark, ((R * K + R + 3) & ~(size_t)3)));      // marks, then the per-rank queue counters
-    c->d_mat_count = c->d_mark + R * K;
-    CHK(dalloc(c, &c->d_mat_list, K));
+    CHK(dalloc(c, &c->d_mark, ((R * K + R + 3) & ~(size_t)3)));      // one mark per node
     CHK(dalloc(c, &c->d_sync, (size_t)c->world));
     CHK(dalloc(c, &c->d_merges, R * Kl * 2));
     CHK(dalloc(c, &c->d_anc, (R > 0 ? R - 1 : 0) * Kl));
@@ -763,7 +757,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
         b.ll_r = c->d_ll + (size_t)r * K;
         b.merges = c->d_merges; b.ancestors = c->d_anc;
         b.child = c->d_child + (size_t)r * Kl * 2; b.aux = c->d_aux;
-        b.lazy = lazy ? 1 : 0; b.mark = c->d_mark; b.child_all = c->d_child; b.Pmat_all = c->d_Pmat; b.mat_list = c->d_mat_list; b.mat_count = c->d_mat_count + r;
+        b.lazy = lazy ? 1 : 0; b.mark = c->d_mark; b.child_all = c->d_child; b.Pmat_all = c->d_Pmat;
         if (twist) {
             pk_twist_args ta{};
             ta.a = b;

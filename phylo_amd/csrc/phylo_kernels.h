@@ -488,7 +488,6 @@ struct pk_rank_args {
     // only when some particle adopts its creator's table at the next resampling (pk_materialize_node)
     int lazy;
     unsigned int* mark;                                   // [R][K] 0/1: node (r, k) is in the pool
-    int32_t* mat_list; unsigned int* mat_count;           // nodes of rank event r-1 adopted at this rank event
     const int32_t* child_all;                             // [R][Kloc][2] children of every node created so far
     const double* Pmat_all;                               // [R][Kloc][32]
     int32_t* child;                                       // [Kloc][2] (row r of child_all): node ids merged at this rank event
