@@ -473,3 +473,23 @@ def test_batched_independent_sweeps_equal_single_sweeps(primate, jc, G, Kg):
     with pytest.raises(_ffi.PhyloError):
         ctx.sweep_batch_async(seeds, flags=_ffi.FLAGS_DEFAULT | _ffi.TWISTING)
     ctx.close()
+
+
+@pytest.mark.parametrize("N,S,G,Kg", [(3, 5, 4, 1), (4, 70, 2, 3), (9, 300, 5, 7)])
+def test_batched_sweeps_edge_shapes(small, N, S, G, Kg):
+    """One particle per group, group sizes that are no multiple of anything, few taxa."""
+    g = small[:N, :S]
+    lam = np.full(N - 1, 10.0)
+    Q = O.get_Q(O.init_y_q())
+    ctx = make_ctx(g, G * Kg, Q)
+    seeds = [3 + 5 * i for i in range(G)]
+    ctx.sweep_batch_async(seeds)
+    out = ctx.sweep_fetch()
+    logz = ctx.sweep_fetch_logz(G)
+    for i, s in enumerate(seeds):
+        ref = CO.sweep(g, Q, PI, lam, lam, Kg, s)
+        sl = slice(i * Kg, (i + 1) * Kg)
+        np.testing.assert_array_equal(out['ancestors'][:, sl], ref['ancestors'])
+        assert_bit_equal(out['log_weights'][:, sl], ref['log_weights'], "log_weights of group %d" % i)
+        assert logz[i] == ref['logZ']
+    ctx.close()
