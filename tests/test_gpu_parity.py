@@ -493,3 +493,58 @@ def test_batched_sweeps_edge_shapes(small, N, S, G, Kg):
         assert_bit_equal(out['log_weights'][:, sl], ref['log_weights'], "log_weights of group %d" % i)
         assert logz[i] == ref['logZ']
     ctx.close()
+
+
+def test_randomised_shapes_and_modes_against_the_oracle():
+    """60 random (N, S, K, model, flags, form) draws: plain / batched sweeps, lazy / eager nodes, JC69 closed form /
+    expm, Q1 quirk on / off, coded / generic leaves -- every one bit-exact against the C oracle."""
+    rng = np.random.default_rng(20261004)
+    for trial in range(60):
+        N = int(rng.integers(2, 15))
+        S = int(rng.choice([1, 3, 63, 64, 65, 127, 256, 257, 300, 513, 900]))
+        G = int(rng.choice([1, 1, 2, 3, 5]))
+        Kg = int(rng.choice([1, 2, 7, 16, 33, 64, 100]))
+        jc = bool(rng.integers(0, 2))
+        q1 = bool(rng.integers(0, 2))
+        eager = bool(rng.integers(0, 2))
+        generic = trial % 7 == 0
+        if generic:
+            g = rng.uniform(0.05, 1.0, size=(N, S, 4))
+        else:
+            codes = rng.integers(0, 5, size=(N, S))
+            g = np.zeros((N, S, 4))
+            for a in range(4):
+                g[..., a] = (codes == a) | (codes == 4)
+        if jc:
+            Q = O.jc_Q()
+        else:
+            y = rng.normal(size=(4, 4)) * 0.4
+            np.fill_diagonal(y, 0.0)
+            Q = O.get_Q(y)
+        p = np.exp(rng.normal(size=4) * 0.3)
+        pi = (p / p.sum())[None, :]
+        lam_l = np.exp(rng.normal(size=N - 1) * 0.3 + 2.0)
+        lam_r = np.exp(rng.normal(size=N - 1) * 0.3 + 2.0)
+        flags = (_ffi.QUIRK_Q1_RAW_Q if q1 else 0) | (_ffi.EAGER_NODES if eager else 0)
+        oflags = O.QUIRK_Q1_RAW_Q if q1 else 0
+        seeds = [int(rng.integers(0, 2 ** 40)) for _ in range(G)]
+        what = "trial %d N=%d S=%d G=%d Kg=%d jc=%s q1=%s eager=%s generic=%s" % (trial, N, S, G, Kg, jc, q1, eager, generic)
+        with _ffi.Context(G * Kg, N, S) as ctx:
+            ctx.set_leaves(g)
+            ctx.set_model(Q, pi, lam_l, lam_r, jc69_closed_form=jc)
+            if G == 1:
+                out = ctx.sweep(seeds[0], flags=flags)
+                logz = [out['logZ']]
+            else:
+                ctx.sweep_batch_async(seeds, flags=flags)
+                out = ctx.sweep_fetch()
+                logz = list(ctx.sweep_fetch_logz(G))
+            node = ctx.sweep_node(N - 2, G * Kg - 1)
+        for i, s in enumerate(seeds):
+            ref = CO.sweep(g, Q, pi, lam_l, lam_r, Kg, s, flags=oflags, jc=jc, want_nodes=(i == G - 1))
+            sl = slice(i * Kg, (i + 1) * Kg)
+            np.testing.assert_array_equal(out['ancestors'][:, sl], ref['ancestors'], err_msg=what)
+            np.testing.assert_array_equal(out['merges'][:, sl], ref['merges'], err_msg=what)
+            assert_bit_equal(out['log_weights'][:, sl], ref['log_weights'], what)
+            assert logz[i] == ref['logZ'] or (np.isnan(logz[i]) and np.isnan(ref['logZ'])), what
+        assert_bit_equal(node, ref['nodes'][N - 2, Kg - 1], what + " last node")
