@@ -477,6 +477,41 @@ int ora_sweep_twisted(const double* genome, const double* Q, const double* pi, c
                                 ora_canon_add(&cs, cp, (double)h[cp] * ora_log(site_lik(pi, o)));
                             }
                             merged_ll = ora_canon_total(&cs);
+                        } else if (coded && ((ls[r1] >= 0) != (ls[r2] >= 0))) {
+                            /* coded leaf x internal root (contract v4): the site likelihood depends on the leaf only through
+                             * its code c, lik[s] = X[s] . v_c with v_c[i] = sum_j P_int[i][j] (pi_j (leaf_c . P_leaf)[j]) */
+                            const int leaf_left = ls[r1] >= 0;
+                            const double* Pleaf = leaf_left ? Pl : Pr;
+                            const double* Pint = leaf_left ? Pr : Pl;
+                            const double* X = leaf_left ? Rr : L;
+                            const uint8_t* cd = codes + (size_t)(leaf_left ? ls[r1] : ls[r2]) * S;
+                            double v[5][4];
+                            for (int c = 0; c < 5; ++c) {
+                                double u[4];
+                                for (int jj = 0; jj < 4; ++jj) {
+                                    const double t = c < 4 ? Pleaf[c * 4 + jj]
+                                                           : ora_fma(1.0, Pleaf[12 + jj], ora_fma(1.0, Pleaf[8 + jj], ora_fma(1.0, Pleaf[4 + jj], 1.0 * Pleaf[jj])));
+                                    u[jj] = pi[jj] * t;
+                                }
+                                for (int i = 0; i < 4; ++i) {
+                                    double acc = Pint[i * 4] * u[0];
+                                    acc = ora_fma(Pint[i * 4 + 1], u[1], acc);
+                                    acc = ora_fma(Pint[i * 4 + 2], u[2], acc);
+                                    v[c][i] = ora_fma(Pint[i * 4 + 3], u[3], acc);
+                                }
+                            }
+                            ora_canon_lp cl;
+                            ora_canon_lp_init(&cl);
+                            for (int s = 0; s < S; ++s) {
+                                const double* x = X + (size_t)s * 4;
+                                const double* vc = v[cd[s]];
+                                double lik = x[0] * vc[0];
+                                lik = ora_fma(x[1], vc[1], lik);
+                                lik = ora_fma(x[2], vc[2], lik);
+                                lik = ora_fma(x[3], vc[3], lik);
+                                ora_canon_lp_mul(&cl, s, lik);
+                            }
+                            merged_ll = ora_canon_lp_total(&cl);
                         } else {
                             for (int s = 0; s < S; ++s) merge_site(L + (size_t)s * 4, Rr + (size_t)s * 4, Pl, Pr, tmp + (size_t)s * 4);
                             merged_ll = row_loglik(pi, tmp, S);

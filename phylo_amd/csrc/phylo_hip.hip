@@ -767,6 +767,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             ta.tw_b = c->d_tw_b; ta.tw_P = c->d_tw_P; ta.pot = c->d_pot; ta.chosen = c->d_chosen;
             ta.Pmat_r = c->d_Pmat + (size_t)r * Kl * 32;
             ta.pair_hist = c->codes_valid ? c->d_pair_hist : nullptr;
+            ta.codes = c->codes_valid ? c->d_leaf_codes : nullptr;
             ta.bl_r = c->d_bl + (size_t)r * Kl; ta.br_r = c->d_br + (size_t)r * Kl;
             hipLaunchKernelGGL(pk_twist_adopt, dim3(K), dim3(64), 0, c->stream, ta);
             CHK(launch_check(c, "pk_twist_adopt"));

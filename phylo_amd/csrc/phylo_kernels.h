@@ -1019,6 +1019,8 @@ struct pk_twist_args {
     double* Pmat_r;                  // [Kloc][32] matrices of the chosen sub-sample (input of pk_rank_merge)
     double* bl_r; double* br_r;      // [Kloc] rows r of the branch-length history
     const uint32_t* pair_hist;       // [N][N][32] or NULL: sites per code pair (c_l * 5 + c_r) of two coded leaves
+    const uint8_t* codes;            // [N][S] leaf codes or NULL: set when the DATA is coded (contracts v3, v4), whichever
+                                     // access path the merge uses
 };
 
 // sites per code pair of every ordered pair of coded leaves: grid (N, N).  Integer LDS atomics (exact).
@@ -1124,6 +1126,28 @@ __device__ __forceinline__ void pk_twist_row(const pk_rank_args& a, const double
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = lpv[j] * rpv[j];
         pm_lp_mul(col, pk_site_lik(pi, o));
+    }
+}
+
+// Contract v4: one (pair, sub-sample) row whose roots are one CODED LEAF and one internal node.  The site likelihood
+// depends on the leaf only through its code c: lik[s] = X[s] . v_c, v_c[i] = sum_j P_int[i][j] (pi_j (leaf_c . P_leaf)[j])
+// (an exact regrouping of pi . ((leaf P_leaf) o (X P_int)); 4 fma per site instead of 24 flops).  vtab = v_c, [5][4].
+__device__ __forceinline__ void pk_twist_row_v4(const pk_rank_args& a, const double* Xp, const uint8_t* cd,
+                                                const double (*vtab)[4], pm_lp& col) {
+    const int tid = threadIdx.x, S = a.S;
+    double Xn[4] = {0, 0, 0, 0};
+    int cn = 0;
+    if (tid < S) { pk_load4(Xp + (size_t)tid * 4, Xn); cn = cd[tid]; }
+    for (int s = tid; s < S; s += PK_COLS) {
+        const double x0 = Xn[0], x1 = Xn[1], x2 = Xn[2], x3 = Xn[3];
+        const int c = cn;
+        if (s + PK_COLS < S) { pk_load4(Xp + (size_t)(s + PK_COLS) * 4, Xn); cn = cd[s + PK_COLS]; }
+        const pk_d2 va = *reinterpret_cast<const pk_d2*>(&vtab[c][0]), vb = *reinterpret_cast<const pk_d2*>(&vtab[c][2]);
+        double lik = x0 * va.x;
+        lik = pm_fma(x1, va.y, lik);
+        lik = pm_fma(x2, vb.x, lik);
+        lik = pm_fma(x3, vb.y, lik);
+        pm_lp_mul(col, lik);
     }
 }
 
@@ -1249,6 +1273,7 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist
     __shared__ double cols[PK_TWIST_LDS_ROWS][PK_COLS];
     __shared__ __attribute__((aligned(16))) double Psh[PK_TWIST_LDS_ROWS][32];
     __shared__ __attribute__((aligned(16))) double tab[PK_TWIST_LDS_ROWS][2][5][4];
+    __shared__ __attribute__((aligned(16))) double vsh[PK_TWIST_LDS_ROWS][5][4];   // contract v4 tables of the staged rows
     __shared__ short rowlist[PK_TWIST_MAX_ROWS];
     __shared__ int nlist;
     const pk_rank_args& a = ta.a;
@@ -1298,10 +1323,32 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist
             pk_build_leaf_table(&Psh[q][side * 16], tab[q][side], e - side * 20);
         }
         __syncthreads();
+        if (ta.codes) {                                   // v4 tables of the rows with exactly one leaf
+            const bool leafL = idl < a.N;
+            for (int i = tid; i < cnt * 20; i += PK_COLS) {
+                const int q = i / 20, e = i - q * 20, c = e >> 2, ii = e & 3;
+                const bool leafR = ro[r1 + 1 + rowlist[base + q] / M] < a.N;
+                if (leafL == leafR) continue;
+                const double (*tl)[4] = tab[q][leafL ? 0 : 1];            // (leaf row of code c) . P_leaf
+                const double* Pint = &Psh[q][leafL ? 16 : 0];            // the internal root's matrix
+                double acc = Pint[ii * 4] * (pi[0] * tl[c][0]);
+                acc = pm_fma(Pint[ii * 4 + 1], pi[1] * tl[c][1], acc);
+                acc = pm_fma(Pint[ii * 4 + 2], pi[2] * tl[c][2], acc);
+                vsh[q][c][ii] = pm_fma(Pint[ii * 4 + 3], pi[3] * tl[c][3], acc);
+            }
+            __syncthreads();
+        }
         for (int q = 0; q < cnt; ++q) {
             const int row = rowlist[base + q], r2 = r1 + 1 + row / M;
             const int idr = ro[r2];
             const double* Rp = pk_node_ptr(a, idr);
+            if (ta.codes && ((idl < a.N) != (idr < a.N))) {       // coded leaf x internal root: contract v4
+                pm_lp colv = pm_lp_init();
+                if (idl < a.N) pk_twist_row_v4(a, Rp, ta.codes + (size_t)idl * a.S, vsh[q], colv);
+                else pk_twist_row_v4(a, Lp, ta.codes + (size_t)idr * a.S, vsh[q], colv);
+                cols[q][tid] = pm_lp_finish(colv);
+                continue;
+            }
             const bool cR = a.leaf_codes && idr < a.N;
             double Pl[16], Pr[16];
 #pragma unroll
