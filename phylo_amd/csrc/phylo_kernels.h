@@ -553,15 +553,27 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
         const double hb_l0 = (local && lane <= a.r) ? a.bl[(size_t)lane * a.Kloc + k] : 0.0;
         const double hb_r0 = (local && lane <= a.r) ? a.br[(size_t)lane * a.Kloc + k] : 0.0;
         const double ldf0 = (lane <= a.ldf_n) ? a.ldf[lane] : 0.0;
+        // the pair keys (one Philox block per four slots) and the resampling draw: ONE evaluation for the wave when the
+        // key blocks leave lane 63 free -- lanes 0..nb-1 take the key blocks, lane 63 the resampling counter
+        const int nb = (n + 3) / 4;
+        uint64_t Rdraw = 0;
+        if (nb <= 63) {
+            const bool res = lane == 63;
+            const pm_u32x4 x = pm_philox4x32(kin, (uint32_t)a.r, res ? PM_STREAM_RESAMPLE : PM_STREAM_PAIR, res ? 0u : (uint32_t)lane, seed);
+            if (lane < nb) { L.key[lane * 4 + 0] = x.x; L.key[lane * 4 + 1] = x.y; L.key[lane * 4 + 2] = x.z; L.key[lane * 4 + 3] = x.w; }
+            Rdraw = ((uint64_t)(uint32_t)__shfl((int)x.y, 63, 64) << 32) | (uint32_t)__shfl((int)x.x, 63, 64);
+        } else {
 #pragma unroll 1
-        for (int b = lane; b < (n + 3) / 4; b += 64) {
-            const pm_u32x4 x = pm_philox4x32(kin, (uint32_t)a.r, PM_STREAM_PAIR, (uint32_t)b, seed);
-            L.key[b * 4 + 0] = x.x; L.key[b * 4 + 1] = x.y; L.key[b * 4 + 2] = x.z; L.key[b * 4 + 3] = x.w;
+            for (int b = lane; b < nb; b += 64) {
+                const pm_u32x4 x = pm_philox4x32(kin, (uint32_t)a.r, PM_STREAM_PAIR, (uint32_t)b, seed);
+                L.key[b * 4 + 0] = x.x; L.key[b * 4 + 1] = x.y; L.key[b * 4 + 2] = x.z; L.key[b * 4 + 3] = x.w;
+            }
+            const pm_u32x4 x = pm_philox4x32(kin, (uint32_t)a.r, PM_STREAM_RESAMPLE, 0u, seed);
+            Rdraw = ((uint64_t)x.y << 32) | x.x;
         }
         int anc = kg;
         if (a.r > 0) {
-            const pm_u32x4 x = pm_philox4x32(kin, (uint32_t)a.r, PM_STREAM_RESAMPLE, 0u, seed);
-            const uint64_t R = ((uint64_t)x.y << 32) | x.x;
+            const uint64_t R = Rdraw;
             if (a.flag) {                             // the scan runs in workgroup 0 of this launch: wait for its flag
                 unsigned int spins = 0;
                 while (__hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
