@@ -98,6 +98,28 @@ def test_sweep_matches_numpy_oracle(jc):
         assert a['logZ'] == pytest.approx(b['logZ'], rel=1e-12)
 
 
+@pytest.mark.parametrize("coded", [True, False])
+def test_twisted_sweep_matches_numpy_oracle(coded):
+    """The C oracle prices the look-ahead potentials of coded leaves by code (contracts v3 / v4: leaf-leaf pairs by
+    code pair, leaf x internal pairs by leaf code); the NumPy oracle sums the reference's formula over sites.  Same
+    trajectories, weights within 1e-9 -- on coded data (both regroupings in use) and on generic data (neither)."""
+    if coded:
+        g = O.form_dataset_from_strings(['ACTTTGAGAGAC', 'ACTTTGACAGTT', 'ACTTTGACTG-A', 'ACTTTGACTCAA', 'AC-TTGACTCGG',
+                                         'GCTTAGACTCGA'], O.ALPHABET_DIR_BLANK)['genome']
+    else:
+        g = np.random.default_rng(8).uniform(0.05, 1.0, size=(6, 12, 4))
+    N = g.shape[0]
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    for K, M, seed in [(6, 1, 0), (10, 3, 5)]:
+        a = O.sweep_twisted(g, Q, PI, lam, lam, K, M, seed)
+        b = CO.sweep_twisted(g, Q, PI, lam, lam, K, M, seed)
+        np.testing.assert_array_equal(a['ancestors'], b['ancestors'])
+        np.testing.assert_array_equal(a['merges'], b['merges'])
+        np.testing.assert_allclose(a['log_weights'], b['log_weights'], rtol=1e-9)
+        assert a['logZ'] == pytest.approx(b['logZ'], rel=1e-10)
+
+
 def test_sweep_is_thread_count_invariant():
     g = O.form_dataset_from_strings(['ACTTTGAGAG', 'ACTTTGACAG', 'ACTTTGACTG', 'ACTTTGACTC'], O.ALPHABET_DIR)['genome']
     lam = np.full(3, 10.0)
