@@ -812,12 +812,20 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                 b.tab_off_cnt = (size_t)24 * K * N + (size_t)cur * K * N * 4;
             }
             c->run.local_book = local_book;
-            hipLaunchKernelGGL(pk_rank_book, dim3(local_book ? Kl : K), dim3(64), lds, c->stream, b);
+            const int nbook = local_book ? Kl : K;
+            if (N <= 16 && !getenv("PHYLO_BOOK_ONE_PER_WAVE"))        // 4 particles per wave (PK_AUX + 2 = 10 <= 16 lanes)
+                hipLaunchKernelGGL(pk_rank_book_packed<16>, dim3(cdiv(nbook, 4)), dim3(64), lds * 4, c->stream, b);
+            else if (N <= 32 && !getenv("PHYLO_BOOK_ONE_PER_WAVE"))   // 2 particles per wave
+                hipLaunchKernelGGL(pk_rank_book_packed<32>, dim3(cdiv(nbook, 2)), dim3(64), lds * 2, c->stream, b);
+            else
+                hipLaunchKernelGGL(pk_rank_book, dim3(nbook), dim3(64), lds, c->stream, b);
             CHK(launch_check(c, "pk_rank_book"));
             ++launches;
         }
         if (lazy && r > 0) {
-            hipLaunchKernelGGL(pk_materialize_adopted, dim3(cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
+            // few nodes are marked, almost every workgroup leaves at once: one workgroup per particle for small nodes (a quarter
+            // of the empty workgroups), site tiles for large ones (a marked node is then not limited to one CU's bandwidth)
+            hipLaunchKernelGGL(pk_materialize_adopted, dim3(S <= 4096 ? 1 : cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
             CHK(launch_check(c, "pk_materialize_adopted"));
             ++launches;
             if (c->comm.transport != 0) {      // peers read these nodes in place: order them before every rank's merge

@@ -709,6 +709,206 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
     __syncthreads();
 }
 
+// ---- packed bookkeeping: LP lanes per particle, 64 / LP particles per wave ---------------------------------------
+// The bookkeeping of one particle is a few short loops over its n <= N root slots; with one wave per particle most
+// lanes idle and the kernel is bound by instruction issue (profiles/r01_merge_pmc.md: 656 VALU + 620 SALU per
+// particle).  For N <= 32 a particle gets LP = 16 or 32 lanes, so one instruction stream serves 4 or 2 particles.
+// Same arithmetic, same orders (the sequential sums stay sequential, on the first lane of each group).
+template <int LP>
+__device__ __forceinline__ int pk_cdf_search_group(const uint64_t* cdf, int K, uint64_t R, int sl, int lane) {
+    const int gshift = lane & ~(LP - 1);
+    const unsigned long long gmask = (1ull << LP) - 1ull;
+    int lo = 0, hi = K;             // invariant: answer in [lo, hi), cdf[hi-1] > thr
+    int step = (K + LP - 1) / LP;
+    int p = (sl + 1) * step - 1;
+    if (p > K - 1) p = K - 1;
+    const uint64_t total = cdf[K - 1];
+    uint64_t c = cdf[p];
+    const uint64_t thr = pm_mulhi64(R, total);
+    bool done = false;
+    for (;;) {
+        const unsigned long long ball = __ballot(!done && c > thr);
+        if (!done) {
+            const unsigned long long mask = (ball >> gshift) & gmask;
+            const int f = mask ? __ffsll((long long)mask) - 1 : LP - 1;
+            int pf = lo + (f + 1) * step - 1;
+            if (pf > hi - 1) pf = hi - 1;
+            lo = lo + f * step;
+            hi = pf + 1;
+            if (lo >= hi) lo = hi - 1;
+            if (hi - lo <= 1) done = true;
+            else {
+                step = (hi - lo + LP - 1) / LP;
+                p = lo + (sl + 1) * step - 1;
+                if (p > hi - 1) p = hi - 1;
+                c = cdf[p];
+            }
+        }
+        if (__all(done)) break;
+    }
+    return lo;
+}
+
+template <int LP>
+__device__ __forceinline__ void pk_book_packed(const pk_rank_args& a, int kg, bool local, const pk_book_lds& L, int sl, int lane) {
+    const int n = a.n, N = a.N, k = kg - a.k0;
+    const int grp = a.group_seeds ? kg / a.Kg : 0;
+    const int gbase = grp * a.Kg;
+    const uint64_t seed = a.group_seeds ? a.group_seeds[grp] : a.seed;
+    const uint32_t kin = (uint32_t)(kg - gbase);
+    {
+        #pragma unroll 1
+        for (int j = sl; j <= a.r; j += LP) {
+            L.hbl[j] = local ? a.bl[(size_t)j * a.Kloc + k] : 0.0;
+            L.hbr[j] = local ? a.br[(size_t)j * a.Kloc + k] : 0.0;
+        }
+        #pragma unroll 1
+        for (int j = sl; j <= a.ldf_n; j += LP) L.ldf[j] = a.ldf[j];
+        // pair keys (lanes 0..nb-1 of the group, nb <= LP / 4) and the resampling draw (last lane): one Philox evaluation
+        const int nb = (n + 3) / 4;
+        const bool res = sl == LP - 1;
+        const pm_u32x4 x = pm_philox4x32(kin, (uint32_t)a.r, res ? PM_STREAM_RESAMPLE : PM_STREAM_PAIR, res ? 0u : (uint32_t)sl, seed);
+        if (sl < nb) { L.key[sl * 4 + 0] = x.x; L.key[sl * 4 + 1] = x.y; L.key[sl * 4 + 2] = x.z; L.key[sl * 4 + 3] = x.w; }
+        const int src = (lane & ~(LP - 1)) + LP - 1;
+        const uint64_t Rdraw = ((uint64_t)(uint32_t)__shfl((int)x.y, src, 64) << 32) | (uint32_t)__shfl((int)x.x, src, 64);
+        int anc = kg;
+        if (a.r > 0) anc = gbase + pk_cdf_search_group<LP>(a.cdf + gbase, a.group_seeds ? a.Kg : a.K, Rdraw, sl, lane);
+        const int32_t* ro = a.roots_old + (size_t)anc * N;
+        const int32_t* co = a.cnt_old + (size_t)anc * N;
+        const double* rl = a.rootll_old + (size_t)anc * N;
+        if (a.tab_ptrs) {                              // the owner of the ancestor holds its rows
+            const char* base = a.tab_ptrs[anc / a.Kloc];
+            ro = reinterpret_cast<const int32_t*>(base + a.tab_off_roots) + (size_t)anc * N;
+            co = reinterpret_cast<const int32_t*>(base + a.tab_off_cnt) + (size_t)anc * N;
+            rl = reinterpret_cast<const double*>(base + a.tab_off_rootll) + (size_t)anc * N;
+        }
+        #pragma unroll 1
+        for (int i = sl; i < n; i += LP) { L.ro[i] = ro[i]; L.co[i] = co[i]; L.anc_ll[i] = rl[i]; }
+        if (sl == 0) {
+            L.misc[3] = anc;
+            if (local) L.aux[AUX_LL_TILDE] = (a.r > 0) ? a.ll_prev[anc] : a.ll_tilde0;
+        }
+    }
+    __syncthreads();
+    {
+        // largest key (lower slot on ties), then the second largest
+        unsigned long long best = 0ull;
+        #pragma unroll 1
+        for (int i = sl; i < n; i += LP) {
+            const unsigned long long c = ((unsigned long long)L.key[i] << 32) | (0xffffffffu - (uint32_t)i);
+            best = c > best ? c : best;
+        }
+#pragma unroll
+        for (int off = 1; off < LP; off <<= 1) {
+            const unsigned long long o = __shfl_xor(best, off, 64);
+            best = o > best ? o : best;
+        }
+        const int il = (int)(0xffffffffu - (uint32_t)best);
+        best = 0ull;
+        #pragma unroll 1
+        for (int i = sl; i < n; i += LP) {
+            const unsigned long long c = ((unsigned long long)L.key[i] << 32) | (0xffffffffu - (uint32_t)i);
+            if (i != il) best = c > best ? c : best;
+        }
+#pragma unroll
+        for (int off = 1; off < LP; off <<= 1) {
+            const unsigned long long o = __shfl_xor(best, off, 64);
+            best = o > best ? o : best;
+        }
+        const int ir = (int)(0xffffffffu - (uint32_t)best);
+        // position of every remaining slot in ascending (key, slot) order
+        int32_t* rn = a.roots_new + (size_t)kg * N;
+        int32_t* cn = a.cnt_new + (size_t)kg * N;
+        double* rln = a.rootll_new + (size_t)kg * N;
+        #pragma unroll 1
+        for (int i = sl; i < n; i += LP) {
+            if (i == il || i == ir) continue;
+            const unsigned long long mine = ((unsigned long long)L.key[i] << 32) | (uint32_t)i;
+            int rank = 0;
+            #pragma unroll 1
+            for (int j = 0; j < n; ++j) {
+                const unsigned long long cj = ((unsigned long long)L.key[j] << 32) | (uint32_t)j;
+                rank += (j != il && j != ir && cj < mine) ? 1 : 0;
+            }
+            const int node = L.ro[i], c = L.co[i];
+            const double xll = L.anc_ll[i];
+            rn[rank] = node;
+            cn[rank] = c;
+            rln[rank] = xll;
+            if (a.pos_hist) a.pos_hist[(size_t)kg * N + i] = rank;
+            L.ord_cnt[rank] = c;
+            L.ord_ll[rank] = xll;
+            L.ord_ldf[rank] = L.ldf[c < a.ldf_n ? c : a.ldf_n];
+        }
+        if (sl == 0) {
+            const int cnew = L.co[il] + L.co[ir];
+            rn[n - 2] = N + a.r * a.K + kg;           // id of the node this particle creates now
+            cn[n - 2] = cnew;
+            L.ord_cnt[n - 2] = cnew;
+            L.ord_ldf[n - 2] = L.ldf[cnew < a.ldf_n ? cnew : a.ldf_n];
+            L.misc[0] = L.ro[il];
+            L.misc[1] = L.ro[ir];
+            if (a.pos_hist) { a.pos_hist[(size_t)kg * N + il] = -1; a.pos_hist[(size_t)kg * N + ir] = -1; }
+            if (local) {
+                a.merges[((size_t)a.r * a.Kloc + k) * 2 + 0] = il;
+                a.merges[((size_t)a.r * a.Kloc + k) * 2 + 1] = ir;
+                if (a.r > 0) a.ancestors[(size_t)(a.r - 1) * a.Kloc + k] = L.misc[3] - gbase;   // index inside the group
+            }
+        }
+    }
+    __syncthreads();
+    if (sl == 0 && local) {                           // sequential sums, LDS operands only (one lane per particle)
+        double sum_rem = 0.0, fprior = 0.0;
+        int vminus = 0;
+        #pragma unroll 1
+        for (int p = 0; p < n - 2; ++p) sum_rem = sum_rem + L.ord_ll[p];
+        #pragma unroll 1
+        for (int p = 0; p < n - 1; ++p) {
+            const int c = L.ord_cnt[p];
+            fprior = fprior + (-L.ord_ldf[p]);
+            vminus += c - (c == 1 ? 1 : 0);
+        }
+        double lp = 0.0, rp = 0.0;                    // history rows 0..r with THIS rank's rate (quirk Q3)
+        #pragma unroll 1
+        for (int j = 0; j <= a.r; ++j) {
+            lp = lp + ((-a.lam_l) * L.hbl[j] + a.loglam_l);
+            rp = rp + ((-a.lam_r) * L.hbr[j] + a.loglam_r);
+        }
+        const double b_l = L.hbl[a.r], b_r = L.hbr[a.r];
+        const double q = 1.0 / ((double)((n - 1) * n) / 2.0);      // 1 / ncr(n, 2), vcsmc.py:298
+        L.aux[AUX_SUM_REM] = sum_rem;
+        L.aux[AUX_FPRIOR] = fprior;
+        L.aux[AUX_LPRIOR] = lp;
+        L.aux[AUX_RPRIOR] = rp;
+        L.aux[AUX_PAREN] = ((a.loglam_l - a.lam_l * b_l) + a.loglam_r) - a.lam_r * b_r;
+        L.aux[AUX_LOGV] = pm_log((double)vminus);
+        L.aux[AUX_Q] = (a.flags & 1u) ? q : pm_log(q);
+    }
+    __syncthreads();
+}
+
+template <int LP>
+__global__ __launch_bounds__(64) void pk_rank_book_packed(const pk_rank_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x, sub = lane / LP, sl = lane & (LP - 1);
+    const int count = a.tab_ptrs ? a.Kloc : a.K;                      // local bookkeeping: this rank's particles only
+    int idx = blockIdx.x * (64 / LP) + sub;
+    if (idx >= count) idx = count - 1;          // a spare group repeats the last particle: identical values, identical writes
+    const int kg = a.tab_ptrs ? a.k0 + idx : idx;
+    const pk_book_lds L = pk_book_carve(smem + (size_t)sub * pk_book_lds_bytes(a.N), a.N);
+    const bool local = kg >= a.k0 && kg < a.k0 + a.Kloc;
+    pk_book_packed<LP>(a, kg, local, L, sl, lane);
+    if (local && sl < PK_AUX + 2) {
+        const int k = kg - a.k0;
+        if (sl < PK_AUX) a.aux[(size_t)k * PK_AUX + sl] = L.aux[sl];
+        else a.child[k * 2 + (sl - PK_AUX)] = L.misc[sl - PK_AUX];
+    }
+    if (a.lazy && a.r > 0 && sl == 0) {
+        const int anc = L.misc[3];
+        a.mark[(size_t)(a.r - 1) * a.K + anc] = 1u;   // plain store: every adopter writes the same value
+    }
+}
+
 // Write node (rho, kappa) into the pool: the same merge, row per thread, no likelihood.  Called by ONE wave.
 __device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int id);
 __device__ __forceinline__ void pk_materialize_node(const pk_rank_args& a, int rho, int kappa, int lane, int nthreads,
@@ -740,7 +940,8 @@ __device__ __forceinline__ void pk_materialize_node(const pk_rank_args& a, int r
 __global__ __launch_bounds__(PK_COLS) void pk_materialize_adopted(const pk_rank_args a) {
     const int node = a.k0 + blockIdx.y;                // grid (site tiles, local particles): unmarked nodes leave at once
     if (!a.mark[(size_t)(a.r - 1) * a.K + node]) return;
-    const int s0 = blockIdx.x * PK_MAT_TILE, s1 = s0 + PK_MAT_TILE < a.S ? s0 + PK_MAT_TILE : a.S;
+    const int tile = (a.S + gridDim.x - 1) / gridDim.x;  // the host picks the tile count (one tile for small nodes)
+    const int s0 = blockIdx.x * tile, s1 = s0 + tile < a.S ? s0 + tile : a.S;
     pk_materialize_node(a, a.r - 1, node, threadIdx.x, PK_COLS, s0, s1);
 }
 
