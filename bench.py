@@ -5,7 +5,7 @@ A "step" is one full sweep (N-1 rank events: draws, transition matrices, resampl
 merges, weights, log Z-hat) over the alignment already resident in HBM.  Default workload: primate.p
 (N=12, S=898), jcmodel=false initial Q (GTR-init), K=2048 particles per GPU.  Throughput form on one GPU:
 independent sweeps (own seed, own resampling, own log Z-hat, each bit-identical to the sweep run alone) are issued
-up to six per set of launches (phylo_sweep_batch_async) on three contexts in flight; `single_sweep_ms` is the
+up to ten per set of launches (phylo_sweep_batch_async) on three contexts in flight; `single_sweep_ms` is the
 latency of one sweep alone.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
@@ -47,7 +47,7 @@ def parse():
                    help='independent sweeps kept in flight on separate HIP streams (0 = 3 on one GPU, 1 when sharded)')
     p.add_argument('--batch', type=int, default=0,
                    help='independent sweeps per set of launches (phylo_sweep_batch_async); 0 = the largest divisor of --steps '
-                        'up to 6 (plain proposal, small nodes), 1 otherwise')
+                        'up to 10 (6 when sharded; plain proposal, small nodes), 1 otherwise')
     p.add_argument('--twisting', action='store_true', help='twisted proposal (vncsmc.py); BASELINE config 2')
     p.add_argument('--M', type=int, default=1, help='sub-samples of the twisted proposal')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -117,7 +117,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     sharded_env = world > 1 or bool(os.environ.get('PHYLO_COMM_FORCE_RCCL'))
     # batching pays where launches are short (small nodes); large nodes fill the GPU with one sweep per launch set
-    batch = a.batch if a.batch > 0 else (6 if not a.twisting and S < 8192 else 1)
+    batch = a.batch if a.batch > 0 else ((6 if sharded_env else 10) if not a.twisting and S < 8192 else 1)
     if a.batch <= 0:                                  # whole launch sets only: the largest divisor of --steps that is <= the default
         while batch > 1 and a.steps % batch:
             batch -= 1

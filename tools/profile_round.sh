@@ -10,8 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- python3 "$REPO/bench.py" --steps 30 --warmup 3 --no-cpu-baseline > "$OUT/trace_default.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_1stream" -- python3 "$REPO/bench.py" --steps 30 --warmup 3 --streams 1 --batch 1 --no-cpu-baseline > "$OUT/trace_1stream.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_1ctx" -- python3 "$REPO/bench.py" --steps 30 --warmup 3 --streams 1 --no-cpu-baseline > "$OUT/trace_1ctx.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 6 --warmup 3 --streams 1 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 6 --warmup 3 --streams 1 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --steps 10 --warmup 10 --streams 1 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --steps 10 --warmup 10 --streams 1 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_twist" -- python3 "$REPO/bench.py" --twisting --M 1 --steps 6 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/trace_twist.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ds1" -- python3 "$REPO/bench.py" --dataset hohna_data_1 --n_particles 4096 --steps 6 --warmup 1 --streams 1 --no-cpu-baseline > "$OUT/trace_ds1.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_train" -- python3 "$REPO/tools/train_probe.py" --steps 10 > "$OUT/trace_train.log" 2>&1
