@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_ran
     const double* Pu = a.Pmat + (size_t)k * 32;
     double Pl[16], Pr[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) { Pl[u] = pk_uniform(Pu[u]); Pr[u] = Pu[16 + u]; }   // P_l in SGPRs, P_r in VGPRs (both would spill)
+    for (int u = 0; u < 16; ++u) { Pl[u] = Pu[u]; Pr[u] = Pu[16 + u]; }   // uniform address, nothing stored yet: scalar loads
     if (codedL || codedR) {
         if (tid < 32) pk_build_leaf_table(Pu, tabL, tid);
         else if (tid < 64) pk_build_leaf_table(Pu + 16, tabR, tid - 32);
