@@ -95,6 +95,7 @@ struct phylo_ctx {
     int last_G = 1;
     bool last_final_missing = false;
     std::vector<uint64_t> h_group_seeds;
+    std::vector<int32_t> h_csr;          // packed integer lists of the reverse pass (kept alive for the async copy)
     hipEvent_t evb0 = nullptr, evb1 = nullptr;
     phylo_stats stats{};
     sweep_run run;
@@ -181,8 +182,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_rootll_ad = c->d_chosen = c->d_tw_b = c->d_tw_P = c->d_pot = nullptr;
     c->tw_capacity = 0;
     void* gr[] = {c->d_hroots, c->d_hcnt, c->d_pos, c->d_hrootll, c->d_adj, c->d_om, c->d_G, c->d_C, c->d_part, c->d_nodeg,
-                  c->d_leafpi, c->d_leafterm, c->d_terms, c->d_gout, c->d_ad_off, c->d_ad_idx, c->d_par_off, c->d_par_idx,
-                  c->d_heavy, c->d_chunk_beg, c->d_chunk_cnt};
+                  c->d_leafpi, c->d_leafterm, c->d_terms, c->d_gout, c->d_ad_off};
     for (void* p : gr)
         if (p) (void)hipFree(p);
     c->d_hroots = c->d_hcnt = c->d_pos = nullptr;
@@ -279,13 +279,16 @@ int ensure_graph_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_leafterm, K * 4));
     CHK(dalloc(c, &c->d_terms, R * K * 2));
     CHK(dalloc(c, &c->d_gout, 2 * R + 20));
-    CHK(dalloc(c, &c->d_ad_off, R * (K + 1)));
-    CHK(dalloc(c, &c->d_ad_idx, R * K));
-    CHK(dalloc(c, &c->d_par_off, R * K + 1));
-    CHK(dalloc(c, &c->d_par_idx, 2 * R * K));
-    CHK(dalloc(c, &c->d_heavy, R * K));
-    CHK(dalloc(c, &c->d_chunk_beg, 2 * R * K / 4 + 1));
-    CHK(dalloc(c, &c->d_chunk_cnt, 2 * R * K / 4 + 1));
+    {   // the integer lists of the reverse pass live in ONE slab, uploaded with one copy per step
+        const size_t cap = 2 * R * K / 4 + 1;
+        CHK(dalloc(c, &c->d_ad_off, R * (K + 1) + R * K + (R * K + 1) + 2 * R * K + R * K + 2 * cap));
+        c->d_ad_idx = c->d_ad_off + R * (K + 1);
+        c->d_par_off = c->d_ad_idx + R * K;
+        c->d_par_idx = c->d_par_off + R * K + 1;
+        c->d_heavy = c->d_par_idx + 2 * R * K;
+        c->d_chunk_beg = c->d_heavy + R * K;
+        c->d_chunk_cnt = c->d_chunk_beg + cap;
+    }
     if (!c->evb0) {
         HIPCHK(c, hipEventCreate(&c->evb0));
         HIPCHK(c, hipEventCreate(&c->evb1));
@@ -343,10 +346,10 @@ int phylo_create(const int* device_ids, int n_gpus, int K, int N, int S, int A, 
         if ((rc = bind(c)) != PHYLO_OK) break;
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(c, PHYLO_EHIP, "hipStreamCreate failed"); break; }
         if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = fail(c, PHYLO_EHIP, "hipEventCreate failed"); break; }
-        if ((rc = dalloc(c, &c->d_Q, 16)) != PHYLO_OK) break;
-        if ((rc = dalloc(c, &c->d_pi, 4)) != PHYLO_OK) break;
-        if ((rc = dalloc(c, &c->d_lam_l, (size_t)N)) != PHYLO_OK) break;
-        if ((rc = dalloc(c, &c->d_lam_r, (size_t)N)) != PHYLO_OK) break;
+        if ((rc = dalloc(c, &c->d_Q, 20 + 2 * (size_t)N)) != PHYLO_OK) break;   // one slab: Q[16] pi[4] lam_l[N] lam_r[N]
+        c->d_pi = c->d_Q + 16;
+        c->d_lam_l = c->d_Q + 20;
+        c->d_lam_r = c->d_Q + 20 + N;
         if ((rc = dalloc(c, &c->d_ldf, (size_t)N + 1)) != PHYLO_OK) break;
         if ((rc = dalloc(c, &c->d_leaves, (size_t)N * S * 4)) != PHYLO_OK) break;
         if ((rc = dalloc(c, &c->d_leaf_codes, (size_t)N * S)) != PHYLO_OK) break;
@@ -370,7 +373,7 @@ int phylo_destroy(phylo_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     phylo_comm_destroy(&c->comm);
     free_sweep_state(c);
-    void* ptrs[] = {c->d_Q, c->d_pi, c->d_lam_l, c->d_lam_r, c->d_ldf, c->d_leaves, c->d_leaf_codes};
+    void* ptrs[] = {c->d_Q, c->d_ldf, c->d_leaves, c->d_leaf_codes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& b : c->scratch)
@@ -426,10 +429,12 @@ int phylo_set_model(phylo_ctx* c, const double* Q16, const double* pi4, const do
     c->h_lam_l.assign(lam_l, lam_l + R);
     c->h_lam_r.assign(lam_r, lam_r + R);
     c->jc = jc69_closed_form ? 1 : 0;
-    HIPCHK(c, hipMemcpyAsync(c->d_Q, Q16, 16 * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_pi, pi4, 4 * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_lam_l, lam_l, (size_t)R * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_lam_r, lam_r, (size_t)R * 8, hipMemcpyHostToDevice, c->stream));
+    std::vector<double> pack(20 + 2 * (size_t)c->N, 0.0);              // one upload for the 42 numbers
+    memcpy(pack.data(), Q16, 16 * 8);
+    memcpy(pack.data() + 16, pi4, 4 * 8);
+    memcpy(pack.data() + 20, lam_l, (size_t)R * 8);
+    memcpy(pack.data() + 20 + c->N, lam_r, (size_t)R * 8);
+    HIPCHK(c, hipMemcpyAsync(c->d_Q, pack.data(), pack.size() * 8, hipMemcpyHostToDevice, c->stream));
     c->have_model = true;
     CHK(refresh_leaf_ll(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1130,15 +1135,21 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     rank_chunk0[R] = (int32_t)chunk_beg.size();
     void* cpart = nullptr;
     CHK(scratch_get(c, 5, max_chunks * (size_t)S * 4 * 8, &cpart));
-    HIPCHK(c, hipMemcpyAsync(c->d_heavy, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice, c->stream));
-    if (!chunk_beg.empty()) {
-        HIPCHK(c, hipMemcpyAsync(c->d_chunk_beg, chunk_beg.data(), chunk_beg.size() * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_chunk_cnt, chunk_cnt.data(), chunk_cnt.size() * 4, hipMemcpyHostToDevice, c->stream));
+    {   // one packed upload (layout of the slab: ad_off | ad_idx | par_off | par_idx | heavy | chunk_beg | chunk_cnt)
+        const size_t cap = 2 * nn / 4 + 1;
+        std::vector<int32_t>& pk = c->h_csr;
+        pk.resize(ad_off.size() + ad_idx.size() + par_off.size() + par_idx.size() + heavy.size() + cap + chunk_cnt.size());
+        int32_t* w = pk.data();
+        memcpy(w, ad_off.data(), ad_off.size() * 4); w += ad_off.size();
+        memcpy(w, ad_idx.data(), ad_idx.size() * 4); w += ad_idx.size();
+        memcpy(w, par_off.data(), par_off.size() * 4); w += par_off.size();
+        memcpy(w, par_idx.data(), par_idx.size() * 4); w += par_idx.size();
+        memcpy(w, heavy.data(), heavy.size() * 4); w += heavy.size();
+        if (!chunk_beg.empty()) memcpy(w, chunk_beg.data(), chunk_beg.size() * 4);
+        w += cap;
+        if (!chunk_cnt.empty()) memcpy(w, chunk_cnt.data(), chunk_cnt.size() * 4);
+        HIPCHK(c, hipMemcpyAsync(c->d_ad_off, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_ad_off, ad_off.data(), ad_off.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_ad_idx, ad_idx.data(), ad_idx.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_par_off, par_off.data(), par_off.size() * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_par_idx, par_idx.data(), par_idx.size() * 4, hipMemcpyHostToDevice, c->stream));
     pg_args g{};
     g.N = N; g.S = S; g.K = K; g.R = R; g.T = T; g.jc = c->jc;
     g.heavy_first = c->d_heavy; g.chunk_beg = c->d_chunk_beg; g.chunk_cnt = c->d_chunk_cnt; g.cpart = (double*)cpart;
