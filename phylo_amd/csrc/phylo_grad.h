@@ -312,11 +312,26 @@ __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) acc[i] = 0.0;
     const int s_end = (tile + 1) * PG_NT < a.S ? (tile + 1) * PG_NT : a.S;
-#pragma unroll 1
-    for (int s = tile * PG_NT + q; s < s_end; s += 64) {
+    // the tile is PG_NT / 64 = 4 steps of 64 sites: all of a thread's loads are issued before the first is used
+    double xs[PG_NT / 64], Ls[PG_NT / 64], Rs[PG_NT / 64];
+#pragma unroll
+    for (int it = 0; it < PG_NT / 64; ++it) {
+        const int s = tile * PG_NT + q + it * 64;
+        xs[it] = Ls[it] = Rs[it] = 0.0;
+        if (s < s_end) {
+            const size_t soff = (size_t)s * 4 + j;
+            xs[it] = xrow[soff];
+            Ls[it] = Lrow[soff];
+            Rs[it] = Rrow[soff];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < PG_NT / 64; ++it) {
+        const int s = tile * PG_NT + q + it * 64;
+        if (s >= s_end) continue;
         const size_t soff = (size_t)s * 4 + j;
-        const double x = xrow[soff];
-        const double Lj = Lrow[soff], Rj = Rrow[soff];
+        const double x = xs[it];
+        const double Lj = Ls[it], Rj = Rs[it];
         const double x0 = pg_quad<0>(x), x1 = pg_quad<1>(x), x2 = pg_quad<2>(x), x3 = pg_quad<3>(x);
         const double lik = ((p0 * x0 + p1 * x1) + p2 * x2) + p3 * x3;
         const double inv = alpha / lik;
