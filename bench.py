@@ -169,7 +169,9 @@ def main():
                     if os.environ.get('PHYLO_BENCH_GROUPED'):
                         _ffi.sweep_step_group(group)
                     else:
-                        for c in group:
+                        for c in group:                   # first halves (lazy nodes: marks, owners' writes, their barrier)
+                            c.sweep_step_a()
+                        for c in group:                   # second halves: bookkeeping, merge, the all-gather, the scan
                             c.sweep_step()
                 for c in group:
                     c.sweep_finish()
@@ -224,9 +226,9 @@ def main():
         merge_ms += st['merge_ms']
         merge_n += st['merge_launches']
     bytes_per_launch = 96.0 * ctx.K_local * S       # 2 child reads + 1 parent write, 32 B each, per (particle, site)
-    # lazy nodes (one GPU, plain proposal, or large nodes when sharded): the launch stores nothing and runs the
-    # row-per-thread form of the merge
-    lazy_nodes = not a.twisting and not os.environ.get('PHYLO_EAGER_NODES') and (world == 1 or S >= 8192)
+    # lazy nodes (plain proposal): the launch stores nothing and runs the row-per-thread form of the merge
+    lazy_nodes = not a.twisting and not os.environ.get('PHYLO_EAGER_NODES') and \
+        (world == 1 or S >= 8192 or bool(os.environ.get('PHYLO_LAZY_NODES')))
     merge_kernel = "pk_rank_merge_nostore" if lazy_nodes else "pk_rank_merge"
     avg_s = merge_ms / merge_n * 1e-3
     achieved = bytes_per_launch / avg_s / 1e9

@@ -158,6 +158,11 @@ int phylo_sweep_fetch_logz(phylo_ctx* ctx, double* logZ_G, int G);
  * sweeps run underneath them. */
 int phylo_sweep_begin(phylo_ctx* ctx, uint64_t seed, uint32_t flags, int M);
 int phylo_sweep_step(phylo_ctx* ctx);
+/* First half of the next rank event on a sharded context with lazy nodes (marking the adopted nodes, the owner's
+ * writes, the collective that orders them before the merges); a no-op otherwise.  phylo_sweep_step runs it itself
+ * when the caller has not: a caller with several contexts in flight issues the first halves of all of them before
+ * the second halves, so that no context's merge waits behind another context's all-gather. */
+int phylo_sweep_step_a(phylo_ctx* ctx);
 /* One rank event of n sweeps that are at the same rank event and share one communicator: the kernels of each on its
  * own stream, then ONE grouped all-gather for all of them, then each sweep's scan. */
 int phylo_sweep_step_group(phylo_ctx** ctxs, int n);

@@ -26,7 +26,7 @@ EXPORTS = [
     "phylo_version", "phylo_last_error", "phylo_device_count", "phylo_create", "phylo_destroy",
     "phylo_set_leaves", "phylo_set_model", "phylo_expm_batched", "phylo_cond_likelihood_K",
     "phylo_forest_loglik", "phylo_tree_loglik", "phylo_resample", "phylo_log_zsmc", "phylo_sweep",
-    "phylo_sweep_async", "phylo_sweep_batch_async", "phylo_sweep_batch_begin", "phylo_sweep_fetch_logz", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_step_group", "phylo_sweep_finish", "phylo_sweep_fetch",
+    "phylo_sweep_async", "phylo_sweep_batch_async", "phylo_sweep_batch_begin", "phylo_sweep_fetch_logz", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_step_a", "phylo_sweep_step_group", "phylo_sweep_finish", "phylo_sweep_fetch",
     "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
     "phylo_math_probe",
     "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_allgather", "phylo_comm_max", "phylo_comm_barrier",
@@ -203,6 +203,9 @@ class Context:
 
     def sweep_step(self):
         self._check(self._lib.phylo_sweep_step(self._h))
+
+    def sweep_step_a(self):
+        self._check(self._lib.phylo_sweep_step_a(self._h))
 
     def sweep_finish(self):
         self._check(self._lib.phylo_sweep_finish(self._h))

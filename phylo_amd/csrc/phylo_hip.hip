@@ -34,6 +34,7 @@ struct sweep_run {                       // a sweep being issued rank event by r
     bool twist = false, graph = false, lazy = false, timek = false, fuse_scan = false, active = false, local_book = false;
     int G = 1;                             // independent sweeps batched in this context (phylo_sweep_batch_async)
     bool final_missing = false;            // the last rank event's nodes were not stored
+    int a_done_r = -1;                     // rank event whose first half (sweep_step_a) has been issued
 };
 
 struct phylo_ctx {
@@ -679,9 +680,11 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
         CHK(ensure_graph_state(c));
     }
     const bool lazy_ok = !twist && !graph && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES");
-    // one GPU: always (marks are plain stores, the extra launch costs less than the dead stores it removes at every
-    // size measured); sharded: only where nodes are large, because the owner's write needs one more collective per
-    // rank event and the bookkeeping of all K particles on every rank
+    // one GPU: always (marks are plain stores, the extra launch costs less than the dead stores it removes at every size
+    // measured).  Sharded: the owner's write needs one more collective per rank event (sweep_step_a); rehearsed on one
+    // GPU the two forms are within 10 % of each other at primate.p's node size and the balance depends on the real
+    // collective latency, so the simpler one-collective form stays the default below the large-node threshold
+    // (PHYLO_LAZY_NODES=1 selects lazy nodes at any size)
     const bool lazy = lazy_ok && (c->world == 1 || S >= 8192 || getenv("PHYLO_LAZY_NODES"));
     int launches = 0;
     const bool fuse_scan = !twist && !graph && G == 1 && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
@@ -710,6 +713,35 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
 
 int phylo_sweep_begin(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) { return sweep_begin_impl(c, seed, flags, M, nullptr, 1); }
 
+// Sharded lazy nodes, first half of a rank event: every rank marks the nodes adopted at this resampling (the search
+// of all K particles, no tables), the owner writes its marked nodes, and one tiny collective orders those writes before
+// every rank's merge.  A no-op otherwise.  phylo_sweep_step runs it when the caller has not (phylo_sweep_step_a).
+static int sweep_step_a(phylo_ctx* c) {
+    CHK(bind(c));
+    if (!c->run.active) return fail(c, PHYLO_ESTATE, "phylo_sweep_step without phylo_sweep_begin");
+    const int N = c->N, K = c->K, Kl = c->Kloc, S = c->S, R = N - 1, r = c->run.next_r;
+    if (r >= R) return fail(c, PHYLO_ESTATE, "all %d rank events of this sweep have been issued", R);
+    c->run.a_done_r = r;
+    if (!(c->world > 1 && c->run.lazy && !c->run.twist && !getenv("PHYLO_REPLICATED_BOOK")) || r == 0) return PHYLO_OK;
+    const int G = c->run.G;
+    pk_rank_args b{};
+    b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
+    b.seed = c->run.seed; b.flags = c->run.flags;
+    b.cdf = c->d_cdf[r & 1];
+    b.Kg = K / G; b.group_seeds = G > 1 ? c->d_group_seeds : nullptr;
+    b.leaves = c->d_leaves; b.pool = c->d_pool; b.pool_ptrs = c->d_pool_ptrs;
+    b.leaf_codes = c->leaves_coded ? c->d_leaf_codes : nullptr;
+    b.lazy = 1; b.mark = c->d_mark; b.child_all = c->d_child; b.Pmat_all = c->d_Pmat;
+    hipLaunchKernelGGL(pk_all_marks, dim3(cdiv(K, 4)), dim3(64), 0, c->stream, b);
+    CHK(launch_check(c, "pk_all_marks"));
+    hipLaunchKernelGGL(pk_materialize_adopted, dim3(S <= 4096 ? 1 : cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
+    CHK(launch_check(c, "pk_materialize_adopted"));
+    double* rows[1] = {c->d_sync};
+    CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
+    c->run.launches += 2;
+    return PHYLO_OK;
+}
+
 // phase 0: the whole rank event; 1: up to and including the merge; 2: what follows the all-gather of the rank
 // event's three K-vectors (phylo_sweep_step_group issues that collective once for several sweeps)
 static int sweep_step_impl(phylo_ctx* c, int phase) {
@@ -728,6 +760,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
     const int G = c->run.G, Kg = K / G;
     const double ll_tilde0 = pm_log(1.0 / (double)Kg);     // vcsmc.py:422
     const int cur = r & 1, nxt = cur ^ 1;
+    if (phase != 2 && c->run.a_done_r != r) CHK(sweep_step_a(c));
     if (phase != 2) {
         pk_rank_args b{};
         b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
@@ -806,10 +839,10 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             CHK(launch_check(c, "pk_rank_scan_book"));
             ++launches;
         } else {
-            // sharded, plain proposal, eager nodes: every rank advances only ITS particles' root tables and reads an
+            // sharded, plain proposal: every rank advances only ITS particles' root tables and reads an
             // adopted ancestor's row from the owner's slab over the peer mapping (ordered by the all-gather of the
             // previous rank event, like the node pool) instead of replicating the bookkeeping of all K particles
-            const bool local_book = c->world > 1 && !lazy && !getenv("PHYLO_REPLICATED_BOOK");
+            const bool local_book = c->world > 1 && !getenv("PHYLO_REPLICATED_BOOK");
             if (local_book) {
                 b.tab_ptrs = c->d_tab_ptrs;
                 b.tab_off_rootll = (size_t)cur * K * N * 8;
@@ -827,7 +860,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             CHK(launch_check(c, "pk_rank_book"));
             ++launches;
         }
-        if (lazy && r > 0) {
+        if (lazy && r > 0 && !(c->run.local_book && !twist)) {   // (sharded with owner-held tables: done in sweep_step_a)
             // few nodes are marked, almost every workgroup leaves at once: one workgroup per particle for small nodes (a quarter
             // of the empty workgroups), site tiles for large ones (a marked node is then not limited to one CU's bandwidth)
             hipLaunchKernelGGL(pk_materialize_adopted, dim3(S <= 4096 ? 1 : cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
@@ -889,6 +922,8 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
 }
 
 int phylo_sweep_step(phylo_ctx* c) { return sweep_step_impl(c, 0); }
+
+int phylo_sweep_step_a(phylo_ctx* c) { return sweep_step_a(c); }
 
 int phylo_sweep_step_group(phylo_ctx** ctxs, int n) {
     if (!ctxs || n < 1) return fail(nullptr, PHYLO_EINVAL, "phylo_sweep_step_group needs at least one context");

@@ -909,6 +909,22 @@ __global__ __launch_bounds__(64) void pk_rank_book_packed(const pk_rank_args a) 
     }
 }
 
+// Sharded lazy nodes: every rank derives the resampling outcome of ALL K particles (index search only, no tables)
+// and marks the adopted ancestors' nodes of the previous rank event, so that each owner knows which of its nodes
+// to write before anybody merges them.  16 lanes per particle.
+__global__ __launch_bounds__(64) void pk_all_marks(const pk_rank_args a) {
+    const int lane = threadIdx.x, sub = lane >> 4, sl = lane & 15;
+    int kg = blockIdx.x * 4 + sub;
+    if (kg >= a.K) kg = a.K - 1;
+    const int grp = a.group_seeds ? kg / a.Kg : 0;
+    const int gbase = grp * a.Kg;
+    const uint64_t seed = a.group_seeds ? a.group_seeds[grp] : a.seed;
+    const pm_u32x4 x = pm_philox4x32((uint32_t)(kg - gbase), (uint32_t)a.r, PM_STREAM_RESAMPLE, 0u, seed);
+    const uint64_t R = ((uint64_t)x.y << 32) | x.x;
+    const int anc = gbase + pk_cdf_search_group<16>(a.cdf + gbase, a.group_seeds ? a.Kg : a.K, R, sl, lane);
+    if (sl == 0) a.mark[(size_t)(a.r - 1) * a.K + anc] = 1u;
+}
+
 // Write node (rho, kappa) into the pool: the same merge, row per thread, no likelihood.  Called by ONE wave.
 __device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int id);
 __device__ __forceinline__ void pk_materialize_node(const pk_rank_args& a, int rho, int kappa, int lane, int nthreads,

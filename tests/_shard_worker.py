@@ -61,6 +61,8 @@ def main():
                     _ffi.sweep_step_group(group)      # one grouped collective per rank event (bench.py's loop)
                 else:
                     for c in group:
+                        c.sweep_step_a()              # first halves of all contexts, then the second halves
+                    for c in group:
                         c.sweep_step()
             for c in group:
                 c.sweep_finish()

@@ -44,13 +44,16 @@ def run_world(world, K, dataset, seed, jc, n_sweeps=1, transport='hostshm', extr
         return outs
 
 
-@pytest.mark.parametrize("world,K,jc,replicated", [(2, 64, True, False), (3, 96, False, False), (2, 64, False, True)])
-def test_sharded_sweep_bit_identical(world, K, jc, replicated):
-    """Default: every rank advances only its own particles' root tables and reads an adopted ancestor's rows from the
-    owner's slab (peer mapping); PHYLO_REPLICATED_BOOK=1: every rank advances all K tables redundantly."""
+@pytest.mark.parametrize("world,K,jc,form", [(2, 64, True, 'default'), (3, 96, False, 'default'), (2, 64, False, 'replicated'),
+                                             (2, 64, False, 'lazy'), (3, 96, True, 'lazy')])
+def test_sharded_sweep_bit_identical(world, K, jc, form):
+    """default: every node stored, every rank advances only its own particles' root tables and reads an adopted ancestor's
+    rows from the owner's slab (peer mapping), one collective per rank event; lazy (PHYLO_LAZY_NODES=1, the default
+    from S >= 8192): adopted nodes are marked from the replicated index search and written by their owner before a
+    barrier collective; replicated (PHYLO_REPLICATED_BOOK=1): every rank advances all K tables redundantly."""
     dataset, seed, n_sweeps = 'primate_data', 4, 2
-    parts = run_world(world, K, dataset, seed, jc, n_sweeps=n_sweeps,
-                      extra_env={'PHYLO_REPLICATED_BOOK': '1'} if replicated else None)
+    env = {'replicated': {'PHYLO_REPLICATED_BOOK': '1'}, 'lazy': {'PHYLO_LAZY_NODES': '1'}}.get(form)
+    parts = run_world(world, K, dataset, seed, jc, n_sweeps=n_sweeps, extra_env=env)
     g = load_dataset(dataset)['genome']
     N = g.shape[0]
     Q = O.jc_Q() if jc else O.get_Q(O.init_y_q())
