@@ -6,7 +6,11 @@ the owner.  Integer state (root tables, leaf counts), two forms:
     the rows of an adopted ancestor are read from the ancestor's OWNER (`comm.gather_tables`, on the GPU a read
     of the owner's table slab over the peer mapping);
   * local_tables=False (PHYLO_REPLICATED_BOOK=1): rows of all K particles are REPLICATED and advanced on every
-    rank from the shared counter-based draws.  Per rank event the ranks all-gather three K-vectors
+    rank from the shared counter-based draws.
+lazy=True (GPU: from S >= 8192, or PHYLO_LAZY_NODES=1): a node is written only when its creator is adopted at the next
+resampling.  Every rank derives all K resampling indices (the weights are replicated), so each owner knows which of its
+nodes of the previous rank event were adopted; it writes them, a barrier orders the writes, then everybody merges.  A
+read of a node that was never written is an error in this model.  Per rank event the ranks all-gather three K-vectors
 (log-weights, log-likelihoods, node log-likelihoods); a child node owned by another rank is fetched from its
 owner when (and only when) it is merged.  `comm` needs all_gather(np.ndarray) -> list of arrays and
 fetch_node(owner, key) (tests wire these to torch.distributed gloo).  The result must equal cpu_ref.sweep.
@@ -18,7 +22,8 @@ import numpy as np
 from . import cpu_ref as O
 
 
-def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, flags=O.QUIRK_Q1_RAW_Q, local_tables=False):
+def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, flags=O.QUIRK_Q1_RAW_Q, local_tables=False,
+                  lazy=False):
     N, S, A = genome.shape
     Kl = K // world
     k0 = rank * Kl
@@ -27,7 +32,8 @@ def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, f
     cnt = np.ones((K, N), dtype=np.int64)
     leaf_ll = np.sum(np.log(np.matmul(genome, pi_1xA[0])), axis=1)
     rootll = np.tile(leaf_ll, (K, 1))
-    pool = {}                                                # (r, k) -> [S,4] for LOCAL k only
+    pool = {}                                                # (r, k) -> [S,4] for LOCAL k only (written nodes)
+    unwritten = {}                                           # lazy: nodes computed for their likelihood but not written
     fetched = 0
     log_weights, log_lik = np.zeros((N - 1, K)), np.zeros((N - 1, K))
     bls, brs = np.zeros((N - 1, Kl)), np.zeros((N - 1, Kl))
@@ -54,6 +60,12 @@ def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, f
                 roots = np.concatenate([p[0] for p in parts])
                 cnt = np.concatenate([p[1] for p in parts])
                 rootll = np.concatenate([p[2] for p in parts])
+            if lazy:                                                     # owners write the nodes adopted just now
+                for a_ in sorted(set(int(v) for v in idx)):
+                    if k0 <= a_ < k0 + Kl and (r - 1, a_) in unwritten:
+                        pool[(r - 1, a_)] = unwritten.pop((r - 1, a_))
+                unwritten.clear()                                        # the rest of that rank event's nodes are dead
+                comm.barrier()
             roots, cnt, rootll = roots[idx], cnt[idx], rootll[idx]
             ll_tilde = log_lik[r - 1, idx]
             ancestors[r - 1] = idx
@@ -72,7 +84,7 @@ def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, f
         new = O.broadcast_conditional_likelihood_K(Q, L, R, bl, br)
         node_ll = np.sum(np.log(np.matmul(new, pi_1xA[0])), axis=1)
         for j in range(Kl):
-            pool[(r, k0 + j)] = new[j]
+            (unwritten if lazy else pool)[(r, k0 + j)] = new[j]
         cnt_new = np.concatenate([cnt_rem, new_cnt[:, None]], axis=1)
         fprior = np.sum(-O.log_double_factorial(2 * np.maximum(cnt_new, 2) - 3), axis=1)
         ll_r = ll_rem[local].sum(axis=1) + node_ll + fprior[local]

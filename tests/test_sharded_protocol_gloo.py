@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _worker(rank, world, port, K, seed, tmp, local_tables):
+def _worker(rank, world, port, K, seed, tmp, local_tables, lazy):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -48,6 +48,9 @@ def _worker(rank, world, port, K, seed, tmp, local_tables):
             dist.all_gather_object(objs, mine)
             return objs
 
+        def barrier(self):
+            dist.barrier()
+
         def serve_begin(self, pool):
             # exchange every rank's full pool (small test sizes) so that fetch_node can be answered locally
             objs = [None] * world
@@ -63,7 +66,7 @@ def _worker(rank, world, port, K, seed, tmp, local_tables):
     g = load_dataset('primate_data_wang')['genome'][:, :120]
     N = g.shape[0]
     Q, pi, lam = O.get_Q(O.init_y_q()), np.full((1, 4), 0.25), np.full(N - 1, 10.0)
-    out = sweep_sharded(Comm(), rank, world, g, Q, pi, lam, lam, K, seed, local_tables=local_tables)
+    out = sweep_sharded(Comm(), rank, world, g, Q, pi, lam, lam, K, seed, local_tables=local_tables, lazy=lazy)
     ref = O.sweep(g, Q, pi, lam, lam, K, seed)
     np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
     np.testing.assert_allclose(out['log_weights'], ref['log_weights'], rtol=1e-12)
@@ -73,11 +76,11 @@ def _worker(rank, world, port, K, seed, tmp, local_tables):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,seed,local_tables", [(16, 0, False), (24, 3, True)])
-def test_sharded_protocol_world2(K, seed, local_tables):
+@pytest.mark.parametrize("K,seed,local_tables,lazy", [(16, 0, False, False), (24, 3, True, False), (24, 5, True, True)])
+def test_sharded_protocol_world2(K, seed, local_tables, lazy):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() * 7 + K) % 1000
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(2, port, K, seed, tmp, local_tables), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, K, seed, tmp, local_tables, lazy), nprocs=2, join=True)
         fetched = sum(int(np.load(os.path.join(tmp, 'fetch%d.npy' % r))[0]) for r in range(2))
         assert fetched > 0, "the test never exercised a remote child"
