@@ -47,7 +47,7 @@ def parse():
                    help='independent sweeps kept in flight on separate HIP streams (0 = 3 on one GPU, 1 when sharded)')
     p.add_argument('--batch', type=int, default=0,
                    help='independent sweeps per set of launches (phylo_sweep_batch_async); 0 = the largest divisor of --steps '
-                        'up to 10 (6 when sharded; plain proposal, small nodes), 1 otherwise')
+                        'up to 10 (plain proposal, small nodes), 1 otherwise')
     p.add_argument('--twisting', action='store_true', help='twisted proposal (vncsmc.py); BASELINE config 2')
     p.add_argument('--M', type=int, default=1, help='sub-samples of the twisted proposal')
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -117,7 +117,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     sharded_env = world > 1 or bool(os.environ.get('PHYLO_COMM_FORCE_RCCL'))
     # batching pays where launches are short (small nodes); large nodes fill the GPU with one sweep per launch set
-    batch = a.batch if a.batch > 0 else ((6 if sharded_env else 10) if not a.twisting and S < 8192 else 1)
+    batch = a.batch if a.batch > 0 else (10 if not a.twisting and S < 8192 else 1)
     if a.batch <= 0:                                  # whole launch sets only: the largest divisor of --steps that is <= the default
         while batch > 1 and a.steps % batch:
             batch -= 1
@@ -227,8 +227,7 @@ def main():
         merge_n += st['merge_launches']
     bytes_per_launch = 96.0 * ctx.K_local * S       # 2 child reads + 1 parent write, 32 B each, per (particle, site)
     # lazy nodes (plain proposal): the launch stores nothing and runs the row-per-thread form of the merge
-    lazy_nodes = not a.twisting and not os.environ.get('PHYLO_EAGER_NODES') and \
-        (world == 1 or S >= 8192 or bool(os.environ.get('PHYLO_LAZY_NODES')))
+    lazy_nodes = not a.twisting and not os.environ.get('PHYLO_EAGER_NODES')
     merge_kernel = "pk_rank_merge_nostore" if lazy_nodes else "pk_rank_merge"
     avg_s = merge_ms / merge_n * 1e-3
     achieved = bytes_per_launch / avg_s / 1e9

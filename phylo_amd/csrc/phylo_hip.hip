@@ -680,12 +680,11 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
         CHK(ensure_graph_state(c));
     }
     const bool lazy_ok = !twist && !graph && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES");
-    // one GPU: always (marks are plain stores, the extra launch costs less than the dead stores it removes at every size
-    // measured).  Sharded: the owner's write needs one more collective per rank event (sweep_step_a); rehearsed on one
-    // GPU the two forms are within 10 % of each other at primate.p's node size and the balance depends on the real
-    // collective latency, so the simpler one-collective form stays the default below the large-node threshold
-    // (PHYLO_LAZY_NODES=1 selects lazy nodes at any size)
-    const bool lazy = lazy_ok && (c->world == 1 || S >= 8192 || getenv("PHYLO_LAZY_NODES"));
+    // marks are plain stores and the extra launch costs less than the dead stores it removes at every size measured.
+    // Sharded, the owner's write needs one more (tiny) collective per rank event (sweep_step_a); rehearsed with a
+    // one-rank RCCL world (PHYLO_REHEARSE_SHARDED=1) the lazy sweep is 0.145 ms against 0.185 ms for the eager one at
+    // primate.p's node size, more than a second collective costs
+    const bool lazy = lazy_ok;
     int launches = 0;
     const bool fuse_scan = !twist && !graph && G == 1 && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
     c->swept = false;
@@ -722,7 +721,8 @@ static int sweep_step_a(phylo_ctx* c) {
     const int N = c->N, K = c->K, Kl = c->Kloc, S = c->S, R = N - 1, r = c->run.next_r;
     if (r >= R) return fail(c, PHYLO_ESTATE, "all %d rank events of this sweep have been issued", R);
     c->run.a_done_r = r;
-    if (!(c->world > 1 && c->run.lazy && !c->run.twist && !getenv("PHYLO_REPLICATED_BOOK")) || r == 0) return PHYLO_OK;
+    const bool shard_form = c->world > 1 || (c->comm.transport != 0 && getenv("PHYLO_REHEARSE_SHARDED"));   // the env: one-rank rehearsal
+    if (!(shard_form && c->run.lazy && !c->run.twist && !getenv("PHYLO_REPLICATED_BOOK")) || r == 0) return PHYLO_OK;
     const int G = c->run.G;
     pk_rank_args b{};
     b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
@@ -842,7 +842,8 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             // sharded, plain proposal: every rank advances only ITS particles' root tables and reads an
             // adopted ancestor's row from the owner's slab over the peer mapping (ordered by the all-gather of the
             // previous rank event, like the node pool) instead of replicating the bookkeeping of all K particles
-            const bool local_book = c->world > 1 && !getenv("PHYLO_REPLICATED_BOOK");
+            const bool local_book = (c->world > 1 || (c->comm.transport != 0 && getenv("PHYLO_REHEARSE_SHARDED"))) &&
+                                    !getenv("PHYLO_REPLICATED_BOOK");
             if (local_book) {
                 b.tab_ptrs = c->d_tab_ptrs;
                 b.tab_off_rootll = (size_t)cur * K * N * 8;

@@ -45,14 +45,14 @@ def run_world(world, K, dataset, seed, jc, n_sweeps=1, transport='hostshm', extr
 
 
 @pytest.mark.parametrize("world,K,jc,form", [(2, 64, True, 'default'), (3, 96, False, 'default'), (2, 64, False, 'replicated'),
-                                             (2, 64, False, 'lazy'), (3, 96, True, 'lazy')])
+                                             (2, 64, False, 'eager'), (3, 96, True, 'eager')])
 def test_sharded_sweep_bit_identical(world, K, jc, form):
-    """default: every node stored, every rank advances only its own particles' root tables and reads an adopted ancestor's
-    rows from the owner's slab (peer mapping), one collective per rank event; lazy (PHYLO_LAZY_NODES=1, the default
-    from S >= 8192): adopted nodes are marked from the replicated index search and written by their owner before a
-    barrier collective; replicated (PHYLO_REPLICATED_BOOK=1): every rank advances all K tables redundantly."""
+    """default: lazy nodes, every rank advances only its own particles' root tables and reads an adopted ancestor's rows
+    from the owner's slab (peer mapping), adopted nodes are marked from the replicated index search and written by their
+    owner before a barrier collective; eager (PHYLO_EAGER_NODES=1): every node stored, one collective per rank event;
+    replicated (PHYLO_REPLICATED_BOOK=1): every rank advances all K tables redundantly."""
     dataset, seed, n_sweeps = 'primate_data', 4, 2
-    env = {'replicated': {'PHYLO_REPLICATED_BOOK': '1'}, 'lazy': {'PHYLO_LAZY_NODES': '1'}}.get(form)
+    env = {'replicated': {'PHYLO_REPLICATED_BOOK': '1'}, 'eager': {'PHYLO_EAGER_NODES': '1'}}.get(form)
     parts = run_world(world, K, dataset, seed, jc, n_sweeps=n_sweeps, extra_env=env)
     g = load_dataset(dataset)['genome']
     N = g.shape[0]
