@@ -11,6 +11,16 @@
  *               SIAM J. Matrix Anal. Appl. 26(4), 2005, Algorithm 2.3 -- what tf.linalg.expm
  *               (tensorflow 1.15, call sites vcsmc.py:183-184) and scipy.linalg.expm (csmc.py:304-305)
  *               implement.
+ *
+ * ora_exp and ora_log restate the algorithms and constants of fdlibm's e_exp.c / e_log.c, whose licence asks that
+ * this notice be preserved:
+ *   ====================================================
+ *   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+ *   Developed at SunPro, a Sun Microsystems, Inc. business.
+ *   Permission to use, copy, modify, and distribute this
+ *   software is freely granted, provided that this notice
+ *   is preserved.
+ *   ====================================================
  */
 #ifndef ORA_MATH_H
 #define ORA_MATH_H

@@ -172,18 +172,29 @@ class CSMC:
         return 1 / rho
 
     def get_tree_prob(self, vertex_dicts, weights_KxNm1, K):
-        """csmc.py:335-349: for every particle, the normalised sum of the last-rank weights of the particles
-        holding the same set of vertices."""
+        """csmc.py:335-349: particle i's probability = mean last-rank weight of the particles holding the same vertex
+        set, divided by the mean last-rank weight (sums run left to right over k, like the reference's loops)."""
         trees = [d.keys() for d in vertex_dicts]
-        last = np.asarray(weights_KxNm1)[:, -1]
-        total = last.sum() / K
-        probs = [sum(last[k] for k in range(K) if trees[k] == t) / K / total for t in trees]
+        last = [float(x) for x in np.asarray(weights_KxNm1)[:, -1]]
+        with np.errstate(all='ignore'):
+            mean_all = np.float64(1 / K) * np.float64(sum(last))
+            probs = []
+            for t in trees:
+                acc = 0.0
+                for k in range(K):
+                    if trees[k] == t:
+                        acc += last[k]
+                probs.append(float(np.float64(acc / K) / mean_all))
         return probs, trees
 
     def compute_norm(self, weights_KxNm1, K):
         """csmc.py:351-355: product over ranks 1..n-2 of the mean weight."""
         w = np.asarray(weights_KxNm1)
-        return float(np.prod([w[:, i].sum() / K for i in range(1, self.n - 1)]))
+        norm = np.float64(1.0)
+        with np.errstate(all='ignore'):
+            for i in range(1, self.n - 1):
+                norm = norm * (np.float64(1 / K) * np.float64(sum(float(x) for x in w[:, i])))
+        return float(norm)
 
     def sample_phylogenies(self, K, resampling=False, showing=True):
         """csmc.py:357-454 with every per-root likelihood evaluated on the GPU.  Same control flow and quirks
@@ -219,7 +230,8 @@ class CSMC:
                 for k in range(K):
                     log_w[k, i] = forest_loglik(forests[k]) - ll_tilda[k] + np.log(self.overcounting_correct(forests[k])) \
                         - np.log(qs[k])
-                    w[k, i] = np.exp(log_w[k, i])
+                    with np.errstate(over='ignore'):
+                        w[k, i] = np.exp(log_w[k, i])      # overflows on real data, as in the reference
             if showing:
                 print('Computation in progress: step ' + str(i + 1))
         tree_probabilities, trees = self.get_tree_prob(forests, w, K)

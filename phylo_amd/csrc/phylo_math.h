@@ -12,6 +12,16 @@
 //   pm_expm4        : Higham 2005 (SIAM J. Matrix Anal. Appl. 26(4)) Pade scaling-and-squaring, the
 //                     algorithm behind tf.linalg.expm (reference call sites vcsmc.py:183-184) and
 //                     scipy.linalg.expm (csmc.py:304-305).
+//
+// pm_exp and pm_log restate the algorithms and constants of fdlibm's e_exp.c / e_log.c, whose licence asks that this
+// notice be preserved:
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
 #pragma once
 #include <stdint.h>
 

@@ -19,6 +19,14 @@ alphabet_dir = {'a': [1, 0, 0, 0], 'c': [0, 1, 0, 0], 'g': [0, 0, 1, 0], 't': [0
 Alphabet_dir_blank = {'A': [1, 0, 0, 0], 'C': [0, 1, 0, 0], 'G': [0, 0, 1, 0], 'T': [0, 0, 0, 1],
                       '-': [1, 1, 1, 1], '?': [1, 1, 1, 1]}
 alphabet = np.array([[1., 0., 0., 0.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]])
+# NOT in the reference (opt-in, `load_dataset(name, ambiguity='iupac')` / `runner.py --ambiguity iupac`): the IUPAC
+# nucleotide codes as indicator rows over (A, C, G, T), so that DS7 (28 'N' cells) loads.  'N' gets the
+# same all-ones row as '-' and '?', the others the set they stand for.
+_IUPAC = {'N': 'ACGT', 'X': 'ACGT', 'R': 'AG', 'Y': 'CT', 'S': 'CG', 'W': 'AT', 'K': 'GT', 'M': 'AC',
+          'B': 'CGT', 'D': 'AGT', 'H': 'ACT', 'V': 'ACG', 'U': 'T'}
+Alphabet_dir_iupac = dict(Alphabet_dir_blank)
+for _c, _set in _IUPAC.items():
+    Alphabet_dir_iupac[_c] = [1 if b in _set else 0 for b in 'ACGT']
 
 
 def load_fasta(path):
@@ -83,10 +91,16 @@ for _i in range(1, 9):
     _FASTA['hohna_data_%d' % _i] = ('hohna_DS%d.fa' % _i, Alphabet_dir_blank)
 
 
-def load_dataset(name):
-    """Dataset table replacing runner.py:81/117-192.  Returns the reference's datadict."""
+def load_dataset(name, ambiguity='error'):
+    """Dataset table replacing runner.py:81/117-192.  Returns the reference's datadict.
+    ambiguity='error' (default) is the reference's behaviour: a character outside the dataset's alphabet raises KeyError
+    (hohna_data_7 holds 'N', runner.py:91-96,107-115); ambiguity='iupac' encodes IUPAC ambiguity codes as indicator rows."""
+    if ambiguity not in ('error', 'iupac'):
+        raise ValueError("ambiguity must be 'error' or 'iupac', got %r" % (ambiguity,))
     if name in _FASTA:
         fname, adir = _FASTA[name]
+        if ambiguity == 'iupac':
+            adir = dict(Alphabet_dir_iupac, **adir)
         _, seqs = load_fasta(os.path.join(DATA_DIR, fname))
         return form_dataset_from_strings(seqs, adir)
     if name == 'load_strings':                                     # runner.py:182-184

@@ -247,19 +247,18 @@ class VCSMC:
         return self.jump_chain_tensor
 
     def batch_slices(self, data, batch_size):
-        """vcsmc.py:453-464 (python's global RNG, like the reference)."""
+        """Site minibatches (vcsmc.py:453-464): S // batch_size draws of batch_size sites without replacement from the
+        sites not used yet, then the leftover sites as a last slice.  Draws come from python's global RNG by
+        random.sample over the unused-site list in CPython set-difference order, so a seeded `random` reproduces the
+        reference's slices."""
         import random
-        sites = data.shape[2]
-        sites_list = list(range(sites))
-        num_batches = sites // batch_size
-        slices = []
-        for i in range(num_batches):
-            sampled_indices = random.sample(sites_list, batch_size)
-            slices.append(sampled_indices)
-            sites_list = list(set(sites_list) - set(sampled_indices))
-        if len(sites_list) != 0:
-            slices.append(sites_list)
-        return slices
+        unused = list(range(data.shape[2]))
+        out = []
+        for _ in range(len(unused) // batch_size):
+            picked = random.sample(unused, batch_size)
+            out.append(picked)
+            unused = list(set(unused) - set(picked))
+        return out + [unused] if unused else out
 
     def newick(self, k=0):
         """Newick string of particle k's final tree, rebuilt from the integer merge records of the last

@@ -3,7 +3,8 @@
 
 Same flags and defaults.  Differences: datasets come from an explicit table
 (phylo_amd/datasets.py) instead of `exec(args.dataset + ' = True')`; `--twisting` is accepted as an alias of
-`--nested` (the reference's README advertises it, its parser lacks it); `--seed` and `--n_gpus` are new.
+`--nested` (the reference's README advertises it, its parser lacks it); `--seed`, `--n_gpus` and `--ambiguity`
+(default: the reference's KeyError on characters such as DS7's 'N'; `iupac` encodes them) are new.
 """
 import argparse
 
@@ -28,6 +29,8 @@ def parse_args(argv=None):
     parser.add_argument('--memory_optimization', help='Use memory optimization?', default='on')
     parser.add_argument('--seed', type=int, default=0, help='seed of the counter-based RNG contract')
     parser.add_argument('--n_gpus', type=int, default=1)
+    parser.add_argument('--ambiguity', choices=('error', 'iupac'), default='error',
+                        help="characters outside the dataset's alphabet: KeyError like the reference, or IUPAC indicator rows")
     args = parser.parse_args(argv)
     if args.twisting is not None:
         args.nested = args.twisting
@@ -38,7 +41,7 @@ def main(argv=None):
     args = parse_args(argv)
     from phylo_amd.datasets import load_dataset
     from phylo_amd.vcsmc import VCSMC
-    datadict = load_dataset(args.dataset)
+    datadict = load_dataset(args.dataset, ambiguity=args.ambiguity)
     vcsmc = VCSMC(datadict, K=args.n_particles, args=args)
     return vcsmc.train(epochs=args.num_epoch, batch_size=args.batch_size, learning_rate=args.learning_rate,
                        memory_optimization=args.memory_optimization)

@@ -14,6 +14,11 @@ What is captured:
   * expm_tables.npz - scipy.linalg.expm(Q t) (the call csmc.py:304-305 makes) for t in 1e-6..10.
   * csmc_resample.npz - CSMC.resample (csmc.py:218-228) on toy weights with numpy's global RNG
                       seeded: the uniforms it consumed and the indices it returned.
+  * csmc_sweeps.npz - CSMC.sample_phylogenies(K, resampling=False, showing=False) (csmc.py:357-454), the only
+                      sweep-level output of the reference that runs here: with resampling off it draws only from
+                      Python's `random` (csmc.py:241,392), so random.seed(s) pins it.  Stored per case:
+                      log_weights[K,n-1], tree_probabilities[K], norm and the vertex ids of the selected tree
+                      (the returned Graph's node names).   `--only sweeps` regenerates this file alone.
 """
 import os
 import sys
@@ -118,7 +123,41 @@ def run_ref_tree(Q, genome, la, ra, bla, bra, root):
     return float(ll), np.array(verts[root].data, dtype=np.float64)
 
 
+def sweep_goldens():
+    """csmc.py:357-454 end to end, seeded through Python's `random` (the reference's only RNG with resampling off)."""
+    import contextlib
+    import io
+    import random
+    toy = ['ACTTTGAGAG', 'ACTTTGACAG', 'ACTTTGACTG', 'ACTTTGACTC']       # csmc.py:477
+    names_small, prim_small = load_fasta(os.path.join(ROOT, 'phylo_amd', 'data', 'primates_small.fa'))
+    sets = {'toy': (['S%d' % i for i in range(4)], encode(toy)),
+            'primates_small': (list(names_small), encode(prim_small))}
+    out, cases = {}, []
+    for dname, (taxa, genome) in sets.items():
+        for K in (4, 8):
+            for seed in (0, 1):
+                c = ref.CSMC({'taxa': list(taxa), 'genome': genome})
+                random.seed(seed)
+                with contextlib.redirect_stdout(io.StringIO()):       # the reference prints its progress
+                    lw, probs, norm, G = c.sample_phylogenies(K, resampling=False, showing=False)
+                tag = '%s/K%d/seed%d' % (dname, K, seed)
+                cases.append(tag)
+                out[tag + '/log_weights'] = np.asarray(lw, dtype=np.float64)
+                out[tag + '/tree_probabilities'] = np.asarray(probs, dtype=np.float64)
+                out[tag + '/norm'] = np.float64(norm)
+                out[tag + '/selected_nodes'] = np.array(sorted(G.get_nodes_data()))
+    for dname, (taxa, genome) in sets.items():
+        out['taxa/' + dname] = np.array(taxa)
+        out['genome/' + dname] = genome
+    out['cases'] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, 'csmc_sweeps.npz'), **out)
+    print('wrote', len(cases), 'sample_phylogenies cases')
+
+
 def main():
+    if '--only' in sys.argv and sys.argv[sys.argv.index('--only') + 1] == 'sweeps':
+        sweep_goldens()
+        return
     out = {}
     qs = q_set()
     rng = np.random.default_rng(20260004)
@@ -191,6 +230,7 @@ def main():
         rs['idx%d' % case] = np.asarray(got, dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, 'csmc_resample.npz'), **rs)
     print('wrote', len(cases), 'tree cases')
+    sweep_goldens()
 
 
 if __name__ == '__main__':

@@ -127,6 +127,88 @@ def test_rccl_single_rank_world(rehearse):
     assert np.array_equal(parts[0]['node'].view(np.uint64), ref['nodes'][7, 31].view(np.uint64))
 
 
+@pytest.mark.parametrize("transport,world,extra", [
+    ('hostshm', 2, {}),                                   # two processes on GPU 0, three sweeps in flight each
+    ('hostshm', 2, {'PHYLO_TEST_GROUP_STEP': '1'}),
+    ('rccl', 1, {'PHYLO_COMM_FORCE_RCCL': '1'}),          # the real library on its dedicated comm stream
+    ('rccl', 1, {'PHYLO_COMM_FORCE_RCCL': '1', 'PHYLO_TEST_GROUP_STEP': '1'}),   # ... one grouped all-gather per rank event
+])
+def test_sweeps_in_flight_share_one_communicator(transport, world, extra):
+    """bench.py's sharded loop: contexts joined by phylo_comm_share advance rank event by rank event; every sweep
+    equals the oracle's sweep of its seed."""
+    K, seed, inflight = 48, 11, 3
+    env = dict(extra, PHYLO_TEST_INFLIGHT=str(inflight))
+    parts = run_world(world, K, 'primate_data', seed, False, n_sweeps=2, transport=transport, extra_env=env)
+    g = load_dataset('primate_data')['genome']
+    N = g.shape[0]
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    ref_last = CO.sweep(g, Q, PI, lam, lam, K, seed + inflight - 1, want_nodes=True)
+    ref_first = CO.sweep(g, Q, PI, lam, lam, K, seed)
+    Kl = K // world
+    for r, p in enumerate(parts):
+        sl = slice(r * Kl, (r + 1) * Kl)
+        np.testing.assert_array_equal(p['ancestors'], ref_last['ancestors'][:, sl])
+        assert np.array_equal(p['log_weights'].view(np.uint64), ref_last['log_weights'][:, sl].view(np.uint64))
+        assert float(p['logZ']) == ref_last['logZ']
+        assert float(p['first_logZ']) == ref_first['logZ']
+        assert np.array_equal(p['node'].view(np.uint64), ref_last['nodes'][N - 2, (r + 1) * Kl - 1].view(np.uint64))
+
+
+@pytest.mark.parametrize("world,G,Kg", [(2, 3, 32), (3, 2, 48)])
+def test_batched_sweeps_on_sharded_contexts(world, G, Kg):
+    """G independent sweeps in ONE sharded context: the G * Kg particle indices are sharded by contiguous ranges (a
+    group straddles ranks when world does not divide G), one all-gather per rank event carries all of them, and
+    every group is bit for bit the Kg-particle sweep of its seed."""
+    seed = 6
+    parts = run_world(world, G * Kg, 'primate_data', seed, False, n_sweeps=2, extra_env={'PHYLO_TEST_BATCH': str(G)})
+    g = load_dataset('primate_data')['genome']
+    N = g.shape[0]
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    refs = [CO.sweep(g, Q, PI, lam, lam, Kg, seed + 10 * i) for i in range(G)]
+    flat = {k: np.concatenate([r[k] for r in refs], axis=1) for k in ('log_weights', 'log_likelihood', 'ancestors', 'merges')}
+    Kl = G * Kg // world
+    for r, p in enumerate(parts):
+        sl = slice(r * Kl, (r + 1) * Kl)
+        np.testing.assert_array_equal(p['ancestors'], flat['ancestors'][:, sl])       # indices inside the group
+        np.testing.assert_array_equal(p['merges'], flat['merges'][:, sl])
+        assert np.array_equal(p['log_weights'].view(np.uint64), flat['log_weights'][:, sl].view(np.uint64))
+        assert np.array_equal(p['log_likelihood'].view(np.uint64), flat['log_likelihood'][:, sl].view(np.uint64))
+        assert list(p['logz']) == [ref['logZ'] for ref in refs]                        # every rank holds every estimate
+
+
+def test_stepwise_sweep_equals_whole_sweep():
+    """phylo_sweep_begin / step / finish, interleaved over two unsharded contexts, against phylo_sweep."""
+    g = load_dataset('primate_data_wang')['genome']
+    N = g.shape[0]
+    lam = np.full(N - 1, 10.0)
+    cs = []
+    for _ in range(2):
+        c = _ffi.Context(40, N, g.shape[1])
+        c.set_leaves(g)
+        c.set_model(O.jc_Q(), PI, lam, lam, jc69_closed_form=True)
+        cs.append(c)
+    whole = [c.sweep(5 + i) for i, c in enumerate(cs)]
+    for i, c in enumerate(cs):
+        c.sweep_begin(5 + i)
+    with pytest.raises(_ffi.PhyloError):
+        cs[0].sweep_finish()                               # not all rank events issued yet
+    for _ in range(N - 1):
+        for c in cs:
+            c.sweep_step()
+    with pytest.raises(_ffi.PhyloError):
+        cs[0].sweep_step()                                 # one too many
+    for c in cs:
+        c.sweep_finish()
+    for i, c in enumerate(cs):
+        out = c.sweep_fetch()
+        assert out['logZ'] == whole[i]['logZ']
+        assert np.array_equal(out['log_weights'].view(np.uint64), whole[i]['log_weights'].view(np.uint64))
+        np.testing.assert_array_equal(out['ancestors'], whole[i]['ancestors'])
+        c.close()
+
+
 def test_comm_init_rejects_bad_world():
     g = load_dataset('primate_data_wang')['genome']
     ctx = _ffi.Context(10, 9, 738)

@@ -30,7 +30,13 @@ def test_dataset_table():
     assert datasets.load_dataset('load_strings')['genome'].shape == (4, 10, 4)
     assert datasets.load_dataset('simulate_data')['genome'].shape == (3, 5, 4)
     with pytest.raises(KeyError):
-        datasets.load_dataset('hohna_data_7')                                  # contains 'N' 
+        datasets.load_dataset('hohna_data_7')                                  # contains 'N' (SURVEY F8): the reference's behaviour
+    d7 = datasets.load_dataset('hohna_data_7', ambiguity='iupac')              # opt-in: 'N' -> all-ones row, like a gap
+    assert d7['genome'].shape == (59, 1824, 4) and int((d7['genome'].sum(axis=2) == 4).sum()) == 28
+    np.testing.assert_array_equal(datasets.form_dataset_from_strings(['RYN'], datasets.Alphabet_dir_iupac)['genome'][0],
+                                  [[1, 0, 1, 0], [0, 1, 0, 1], [1, 1, 1, 1]])
+    np.testing.assert_array_equal(datasets.load_dataset('hohna_data_1', ambiguity='iupac')['genome'],
+                                  datasets.load_dataset('hohna_data_1')['genome'])
     with pytest.raises(FileNotFoundError):
         datasets.load_dataset('corona_data')
     with pytest.raises(ValueError):

@@ -61,3 +61,22 @@ def test_adam_update_rule_tf1_defaults():
     np.testing.assert_allclose(v.a_l[0], 0.01 - lr_t * m / (np.sqrt(s) + 1e-8), rtol=1e-6)
     assert str(opt).startswith('AdamOptimizer') and str(T.make_optimizer('x', 0.1)).startswith('GradientDescent')
     assert isinstance(T.make_optimizer('Adam', 0.1), T.Adam)
+
+
+def test_batch_slices_partition_and_rng_sequence():
+    """vcsmc.py:453-464: S // b slices of b sites drawn without replacement from the unused sites (python's global RNG),
+    then the leftover; with b >= S there is only the leftover slice, so no training step runs (quirk Q9)."""
+    import random
+    from phylo_amd.vcsmc import VCSMC
+    S, b = 898, 256
+    data = np.zeros((1, 12, S, 4))
+    random.seed(3)
+    slices = VCSMC.batch_slices(None, data, b)
+    assert [len(s) for s in slices] == [256, 256, 256, 130]
+    assert sorted(sum(slices, [])) == list(range(S))                       # a partition of the sites
+    random.seed(3)
+    assert slices[0] == random.sample(list(range(S)), b)                   # first draw: straight from the RNG stream
+    rest = list(set(range(S)) - set(slices[0]))
+    assert slices[1] == random.sample(rest, b)                             # second draw: over the set-difference order
+    assert [len(s) for s in VCSMC.batch_slices(None, data, 1000)] == [898]
+    assert [len(s) for s in VCSMC.batch_slices(None, np.zeros((1, 2, 512, 4)), 256)] == [256, 256]
