@@ -55,6 +55,11 @@ enum {
                                           either (phylo_sweep_node writes them on demand) unless this flag is set */
     PHYLO_KEEP_GRAPH = 1u << 4,        /* keep what phylo_sweep_backward needs (root-table history of every rank
                                           event, every node); one GPU, plain proposal; implies PHYLO_EAGER_NODES */
+    PHYLO_ONE_LAUNCH = 1u << 5,        /* run the whole sweep as ONE launch of resident workgroups (phylo_persist.h) where that
+                                          form applies (phylo_sweep_async / phylo_sweep_batch_async on one GPU, plain proposal,
+                                          N <= 32, small nodes) instead of launches per rank event (scan, bookkeeping,
+                                          materialise, merge).  Same bits either way; PHYLO_ONE_LAUNCH=1 in the environment of
+                                          phylo_create sets it for every sweep of the context.  */
     PHYLO_FLAGS_DEFAULT = PHYLO_QUIRK_Q1_RAW_Q
 };
 
@@ -182,6 +187,11 @@ int phylo_sweep_node(phylo_ctx* ctx, int r, int k, double* out_Sx4);
  * perf (may be NULL): sweep_ms = device time of the reverse pass. */
 int phylo_sweep_backward(phylo_ctx* ctx, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q,
                          phylo_stats* perf);
+
+/* Diagnostics of the one-launch sweep: with PHYLO_PERSIST_STAMPS=1 in the environment when the context is created,
+ * workgroup 0 stamps s_memrealtime (100 MHz ticks) at its phase boundaries; out receives [N][16] values (rows 0..N-2: rank
+ * events; row N-1: prologue).  No effect on results; not for timed runs. */
+int phylo_debug_stamps(phylo_ctx* ctx, uint64_t* out, int n);
 
 /* Bit-level probe of the device arithmetic contract: op 0 exp(x), 1 log(x), 2 x/y, 3 fma(x,y,x). */
 int phylo_math_probe(phylo_ctx* ctx, int op, const double* x, const double* y, int n, double* out);

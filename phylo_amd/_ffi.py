@@ -19,6 +19,7 @@ TWISTING = 1 << 1
 TIME_KERNELS = 1 << 2
 EAGER_NODES = 1 << 3
 KEEP_GRAPH = 1 << 4
+ONE_LAUNCH = 1 << 5
 FLAGS_DEFAULT = QUIRK_Q1_RAW_Q
 COMM_ID_BYTES = 128
 
@@ -28,7 +29,7 @@ EXPORTS = [
     "phylo_forest_loglik", "phylo_tree_loglik", "phylo_resample", "phylo_log_zsmc", "phylo_sweep",
     "phylo_sweep_async", "phylo_sweep_batch_async", "phylo_sweep_batch_begin", "phylo_sweep_fetch_logz", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_step_a", "phylo_sweep_step_group", "phylo_sweep_finish", "phylo_sweep_fetch",
     "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
-    "phylo_math_probe",
+    "phylo_math_probe", "phylo_debug_stamps",
     "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_allgather", "phylo_comm_max", "phylo_comm_barrier",
 ]
 
@@ -248,6 +249,12 @@ class Context:
         self._check(self._lib.phylo_sweep_backward(self._h, _ptr(out['d_lam_l']), _ptr(out['d_lam_r']), _ptr(out['d_pi']),
                                                    _ptr(out['d_Q']), C.byref(st)))
         out['backward_ms'] = st.sweep_ms
+        return out
+
+    def debug_stamps(self):
+        """[N][16] s_memrealtime ticks (100 MHz) of workgroup 0 of the last one-launch sweep (PHYLO_PERSIST_STAMPS=1)."""
+        out = np.zeros((self.N, 16), dtype=np.uint64)
+        self._check(self._lib.phylo_debug_stamps(self._h, _ptr(out), C.c_int(out.size)))
         return out
 
     # ---- multi-GPU

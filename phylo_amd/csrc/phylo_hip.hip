@@ -9,11 +9,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "phylo_comm.h"
 #include "phylo_kernels.h"
+#include "phylo_persist.h"
 #include "phylo_grad.h"
 
 namespace {
@@ -37,8 +39,42 @@ struct sweep_run {                       // a sweep being issued rank event by r
     int a_done_r = -1;                     // rank event whose first half (sweep_step_a) has been issued
 };
 
+// A/B switches of DESIGN.md section 6b, read from the environment ONCE (phylo_create): none changes a result bit
+struct env_switches {
+    bool eager_nodes = false, rehearse_sharded = false, replicated_book = false, fuse_scan = false,
+         book_one_per_wave = false, merge_pair_form = false, no_leaf_codes = false, one_launch = false,
+         persist_stamps = false;
+    int persist_wgs = 0;                 // PHYLO_PERSIST_WGS: resident workgroups of the one-launch sweep (0 = default)
+    int persist_nt = 256;                // PHYLO_PERSIST_NT: threads per workgroup of the one-launch sweep (256 or 512)
+    void read() {
+        eager_nodes = getenv("PHYLO_EAGER_NODES") != nullptr;
+        rehearse_sharded = getenv("PHYLO_REHEARSE_SHARDED") != nullptr;
+        replicated_book = getenv("PHYLO_REPLICATED_BOOK") != nullptr;
+        fuse_scan = getenv("PHYLO_FUSE_SCAN") != nullptr;
+        book_one_per_wave = getenv("PHYLO_BOOK_ONE_PER_WAVE") != nullptr;
+        merge_pair_form = getenv("PHYLO_MERGE_PAIR_FORM") != nullptr;
+        no_leaf_codes = getenv("PHYLO_NO_LEAF_CODES") != nullptr;
+        one_launch = getenv("PHYLO_ONE_LAUNCH") != nullptr;
+        persist_stamps = getenv("PHYLO_PERSIST_STAMPS") != nullptr;
+        const char* w = getenv("PHYLO_PERSIST_WGS");
+        persist_wgs = w ? atoi(w) : 0;
+        const char* t = getenv("PHYLO_PERSIST_NT");
+        persist_nt = (t && atoi(t) == 512) ? 512 : 256;
+    }
+};
+
 struct phylo_ctx {
     int device = 0;
+    env_switches env;
+    int n_cus = 0;                       // compute units of the device
+    // one-launch sweep (phylo_persist.h)
+    unsigned long long* d_rdraw = nullptr;   // [(N-1)][K] resampling draws
+    unsigned long long* d_pctr = nullptr;    // [PK_MAX_GROUPS][PP_CTR_STRIDE] monotone arrival counters
+    unsigned long long pctr_base = 0;        // their common value (every group receives Wg arrivals per rank event)
+    int pctr_Wg = 0;                         // workgroups per group the counters were last used with
+    int persist_blocks_per_cu = -1;          // occupancy of pp_sweep (-1: not asked yet)
+    bool last_persistent = false;
+    unsigned long long* d_stamps = nullptr;  // phase stamps of the one-launch sweep (PHYLO_PERSIST_STAMPS=1)
     int K = 0, N = 0, S = 0, A = 4;      // K = global particle count
     int Kloc = 0, k0 = 0;                // this rank's shard
     int rank = 0, world = 1;
@@ -193,6 +229,13 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_heavy = c->d_chunk_beg = c->d_chunk_cnt = nullptr;
     c->graph_ready = false;
     c->last_graph = false;
+    if (c->d_stamps) (void)hipFree(c->d_stamps);
+    c->d_stamps = nullptr;
+    if (c->d_rdraw) (void)hipFree(c->d_rdraw);
+    if (c->d_pctr) (void)hipFree(c->d_pctr);
+    c->d_rdraw = c->d_pctr = nullptr;
+    c->pctr_base = 0;
+    c->pctr_Wg = 0;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse, c->d_group_seeds,
                     c->d_tables, (void*)c->d_tab_ptrs, c->d_child, c->d_merges, c->d_anc,
                     c->d_cdf[0], c->d_cdf[1], c->d_counter, (void*)c->d_pool_ptrs, c->d_mark, c->d_sync};
@@ -342,9 +385,15 @@ int phylo_create(const int* device_ids, int n_gpus, int K, int N, int S, int A, 
     c->K = K; c->N = N; c->S = S; c->A = A;
     c->Kloc = K; c->k0 = 0;
     c->flags = flags;
+    c->env.read();
     int rc = PHYLO_OK;
     do {
         if ((rc = bind(c)) != PHYLO_OK) break;
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { rc = fail(c, PHYLO_EHIP, "hipGetDeviceProperties failed"); break; }
+            c->n_cus = prop.multiProcessorCount;
+        }
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = fail(c, PHYLO_EHIP, "hipStreamCreate failed"); break; }
         if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { rc = fail(c, PHYLO_EHIP, "hipEventCreate failed"); break; }
         if ((rc = dalloc(c, &c->d_Q, 20 + 2 * (size_t)N)) != PHYLO_OK) break;   // one slab: Q[16] pi[4] lam_l[N] lam_r[N]
@@ -410,7 +459,7 @@ int phylo_set_leaves(phylo_ctx* c, const double* genome) {
             else ok = false;
         }
         c->codes_valid = ok;                                  // a property of the data (the twisting contract uses it)
-        c->leaves_coded = ok && !getenv("PHYLO_NO_LEAF_CODES");   // the access-path optimisation can be switched off
+        c->leaves_coded = ok && !c->env.no_leaf_codes;   // the access-path optimisation can be switched off
         c->hist_ready = false;
         if (ok) HIPCHK(c, hipMemcpy(c->d_leaf_codes, codes.data(), rows, hipMemcpyHostToDevice));
     }
@@ -679,14 +728,14 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
         if (c->world != 1) return fail(c, PHYLO_EINVAL, "PHYLO_KEEP_GRAPH needs an unsharded context");
         CHK(ensure_graph_state(c));
     }
-    const bool lazy_ok = !twist && !graph && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES");
+    const bool lazy_ok = !twist && !graph && !(flags & PHYLO_EAGER_NODES) && !c->env.eager_nodes;
     // marks are plain stores and the extra launch costs less than the dead stores it removes at every size measured.
     // Sharded, the owner's write needs one more (tiny) collective per rank event (sweep_step_a); rehearsed with a
     // one-rank RCCL world (PHYLO_REHEARSE_SHARDED=1) the lazy sweep is 0.145 ms against 0.185 ms for the eager one at
     // primate.p's node size, more than a second collective costs
     const bool lazy = lazy_ok;
     int launches = 0;
-    const bool fuse_scan = !twist && !graph && G == 1 && getenv("PHYLO_FUSE_SCAN");   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
+    const bool fuse_scan = !twist && !graph && G == 1 && c->env.fuse_scan;   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
     c->swept = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (lazy) HIPCHK(c, hipMemsetAsync(c->d_mark, 0, (((size_t)R * K + R + 3) & ~(size_t)3) * sizeof(unsigned int), c->stream));
@@ -710,6 +759,128 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     return PHYLO_OK;
 }
 
+
+// ---- the sweep as ONE launch (phylo_persist.h) ------------------------------------------------------------------
+// Resident-workgroup kernels of different contexts must not be dispatched together: each waits inside the launch for ALL of
+// its own workgroups, and two partially resident grids would wait for each other's CU slots for ever (the bounded spins turn
+// that into a timeout error, not a hang).  So the one-launch sweeps of a process run one after the other on a device: every
+// launch waits for the event the previous one recorded.  (Kernels of the launch path still overlap with them freely.)
+static std::mutex g_persist_mu;
+static hipEvent_t g_persist_done[64] = {};
+static int persist_chain(phylo_ctx* c, bool after_launch) {
+    std::lock_guard<std::mutex> lock(g_persist_mu);
+    if (c->device < 0 || c->device >= 64) return fail(c, PHYLO_EINVAL, "device id out of range for the one-launch sweep");
+    hipEvent_t& ev = g_persist_done[c->device];
+    if (!after_launch) {
+        if (ev) HIPCHK(c, hipStreamWaitEvent(c->stream, ev, 0));
+        return PHYLO_OK;
+    }
+    if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(ev, c->stream));
+    return PHYLO_OK;
+}
+
+// Plan: G groups x Wg resident workgroups, m = Kg / Wg particles each.  Returns false when this context / sweep is
+// not eligible (the launch-per-rank-event path runs instead).
+static bool persist_plan(phylo_ctx* c, uint32_t flags, int G, int* Wg_out, int* m_out) {
+    if (!(c->env.one_launch || (flags & PHYLO_ONE_LAUNCH))) return false;             // opt-in
+    if (c->world != 1 || c->comm.transport != 0) return false;                       // sharded: collectives between launches
+    if (flags & (PHYLO_TWISTING | PHYLO_KEEP_GRAPH | PHYLO_EAGER_NODES | PHYLO_TIME_KERNELS)) return false;   // launch path only
+    if (c->env.eager_nodes || c->env.fuse_scan || c->env.merge_pair_form || c->env.book_one_per_wave) return false;   // A/B switches of the launch path
+    if (c->N > 32 || c->N < 2) return false;                                        // one wave per particle: a lane per root slot, history rows in lanes
+    const int Kg = c->K / G;
+    if (Kg > PP_MAX_KG) return false;                                               // the group's cdf lives in LDS
+    // large nodes: the launch path spreads one node over several workgroups and its launches are long enough
+    if ((double)c->S * 32.0 > 256.0 * 1024.0) return false;
+    if (c->persist_blocks_per_cu < 0) {
+        // residency of ONE workgroup per CU is all the kernel needs; ask the runtime whether it is admitted at all
+        int nb = 0;
+        const size_t lds = pp_layout(c->N, PP_CHUNK, 2048).total;
+        hipError_t e = c->env.persist_nt == 512
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pp_sweep<512>, 512, lds)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pp_sweep<256>, 256, lds);
+        c->persist_blocks_per_cu = (e == hipSuccess && nb >= 1) ? (nb >= 3 ? 2 : 1) : 0;   // one workgroup per CU by default; two only with a block of margin
+    }
+    if (c->persist_blocks_per_cu < 1 || c->n_cus < 1) return false;
+    int Wt = c->env.persist_wgs > 0 ? c->env.persist_wgs : c->n_cus;                // default: one workgroup per CU
+    if (Wt > c->n_cus * c->persist_blocks_per_cu) Wt = c->n_cus * c->persist_blocks_per_cu;
+    if (Wt < G) return false;
+    int Wg = Wt / G;
+    if (Wg > Kg) Wg = Kg;
+    while (Wg > 1 && Kg % Wg) --Wg;
+    const int m = Kg / Wg;
+    if (m > PP_MAX_M) return false;
+    if (pp_layout(c->N, m, Kg).total > 150 * 1024) return false;
+    *Wg_out = Wg;
+    *m_out = m;
+    return true;
+}
+
+static int sweep_persistent(phylo_ctx* c, uint64_t seed, uint32_t flags, const uint64_t* group_seeds, int G, int Wg, int m) {
+    CHK(bind(c));
+    c->run.active = false;
+    if (!c->have_leaves || !c->have_model)
+        return fail(c, PHYLO_ESTATE, "phylo_set_leaves and phylo_set_model must be called before a sweep");
+    if (!c->state_ready) {
+        CHK(ensure_sweep_state(c));
+        CHK(refresh_leaf_ll(c));
+    }
+    const int N = c->N, K = c->K, S = c->S, R = N - 1, Kg = K / G;
+    if (!c->d_rdraw) {
+        CHK(dalloc(c, &c->d_rdraw, (size_t)R * K));
+        CHK(dalloc(c, &c->d_pctr, (size_t)PK_MAX_GROUPS * PP_CTR_STRIDE));
+        HIPCHK(c, hipMemsetAsync(c->d_pctr, 0, (size_t)PK_MAX_GROUPS * PP_CTR_STRIDE * 8, c->stream));
+        c->pctr_base = 0;
+        c->pctr_Wg = Wg;
+    }
+    if (c->pctr_Wg != Wg) {                                // another grid shape: restart the monotone counters
+        HIPCHK(c, hipMemsetAsync(c->d_pctr, 0, (size_t)PK_MAX_GROUPS * PP_CTR_STRIDE * 8, c->stream));
+        c->pctr_base = 0;
+        c->pctr_Wg = Wg;
+    }
+    pp_args a{};
+    a.N = N; a.S = S; a.K = K; a.Kg = Kg; a.G = G; a.R = R; a.Wg = Wg; a.m = m;
+    a.seed = seed; a.flags = flags; a.jc = c->jc;
+    if (G > 1) {
+        HIPCHK(c, hipMemcpyAsync(c->d_group_seeds, group_seeds, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
+        a.group_seeds = c->d_group_seeds;
+    }
+    a.Q = c->d_Q; a.lam_l = c->d_lam_l; a.lam_r = c->d_lam_r; a.pi = c->d_pi; a.ldf = c->d_ldf;
+    a.leaves = c->d_leaves; a.leaf_codes = c->leaves_coded ? c->d_leaf_codes : nullptr; a.pool = c->d_pool;
+    for (int i = 0; i < 2; ++i) { a.roots[i] = c->d_roots[i]; a.cnt[i] = c->d_cnt[i]; a.rootll[i] = c->d_rootll[i]; }
+    a.nodell = c->d_nodell; a.bl = c->d_bl; a.br = c->d_br; a.Pmat = c->d_Pmat; a.logw = c->d_logw; a.ll = c->d_ll;
+    a.child = c->d_child; a.merges = c->d_merges; a.anc = c->d_anc; a.mark = c->d_mark;
+    a.rdraw = c->d_rdraw;
+    a.lse = c->d_lse; a.lse_stride = R + 1;
+    a.ctr = c->d_pctr; a.ctr_base = c->pctr_base;
+    a.timeout_word = c->d_counter + 1;
+    if (c->env.persist_stamps) {
+        if (!c->d_stamps) CHK(dalloc(c, &c->d_stamps, (size_t)(R + 1) * PP_NSTAMP));
+        a.stamps = c->d_stamps;
+    }
+    const size_t lds = pp_layout(N, m, Kg).total;
+    c->swept = false;
+    CHK(persist_chain(c, false));
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (c->env.persist_nt == 512) hipLaunchKernelGGL((pp_sweep<512>), dim3(G * Wg), dim3(512), lds, c->stream, a);
+    else hipLaunchKernelGGL((pp_sweep<256>), dim3(G * Wg), dim3(256), lds, c->stream, a);
+    CHK(launch_check(c, "pp_sweep"));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    CHK(persist_chain(c, true));
+    c->pctr_base += (unsigned long long)R * Wg;
+    c->swept = true;
+    c->last_lazy = true;                                   // only adopted nodes are in the pool (marks say which)
+    c->last_graph = false;
+    c->last_G = G;
+    c->last_final_missing = false;
+    c->last_persistent = true;
+    c->n_merge_events = 0;
+    c->stats.n_launches = 1;
+    c->stats.units = (double)K * S * R;
+    c->stats.alg_bytes = 96.0 * c->stats.units;
+    return PHYLO_OK;
+}
+
 int phylo_sweep_begin(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) { return sweep_begin_impl(c, seed, flags, M, nullptr, 1); }
 
 // Sharded lazy nodes, first half of a rank event: every rank marks the nodes adopted at this resampling (the search
@@ -721,8 +892,8 @@ static int sweep_step_a(phylo_ctx* c) {
     const int N = c->N, K = c->K, Kl = c->Kloc, S = c->S, R = N - 1, r = c->run.next_r;
     if (r >= R) return fail(c, PHYLO_ESTATE, "all %d rank events of this sweep have been issued", R);
     c->run.a_done_r = r;
-    const bool shard_form = c->world > 1 || (c->comm.transport != 0 && getenv("PHYLO_REHEARSE_SHARDED"));   // the env: one-rank rehearsal
-    if (!(shard_form && c->run.lazy && !c->run.twist && !getenv("PHYLO_REPLICATED_BOOK")) || r == 0) return PHYLO_OK;
+    const bool shard_form = c->world > 1 || (c->comm.transport != 0 && c->env.rehearse_sharded);   // the env: one-rank rehearsal
+    if (!(shard_form && c->run.lazy && !c->run.twist && !c->env.replicated_book) || r == 0) return PHYLO_OK;
     const int G = c->run.G;
     pk_rank_args b{};
     b.r = r; b.n = N - r; b.N = N; b.S = S; b.K = K; b.Kloc = Kl; b.k0 = c->k0;
@@ -767,7 +938,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
         b.seed = seed; b.flags = flags;
         b.Kg = Kg; b.group_seeds = G > 1 ? c->d_group_seeds : nullptr;
         // the node of the LAST rank event is never merged again: its log-likelihood is all the sweep needs
-        b.no_store = (r == R - 1 && !graph && !(flags & PHYLO_EAGER_NODES) && !getenv("PHYLO_EAGER_NODES")) ? 1 : 0;
+        b.no_store = (r == R - 1 && !graph && !(flags & PHYLO_EAGER_NODES) && !c->env.eager_nodes) ? 1 : 0;
         if (r == R - 1) c->run.final_missing = b.no_store && !lazy;
         if (graph) {                                       // every rank event keeps its tables: plane r -> plane r + 1
             b.roots_old = c->d_hroots + plane * r; b.cnt_old = c->d_hcnt + plane * r;
@@ -842,8 +1013,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             // sharded, plain proposal: every rank advances only ITS particles' root tables and reads an
             // adopted ancestor's row from the owner's slab over the peer mapping (ordered by the all-gather of the
             // previous rank event, like the node pool) instead of replicating the bookkeeping of all K particles
-            const bool local_book = (c->world > 1 || (c->comm.transport != 0 && getenv("PHYLO_REHEARSE_SHARDED"))) &&
-                                    !getenv("PHYLO_REPLICATED_BOOK");
+            const bool local_book = (c->world > 1 || (c->comm.transport != 0 && c->env.rehearse_sharded)) && !c->env.replicated_book;
             if (local_book) {
                 b.tab_ptrs = c->d_tab_ptrs;
                 b.tab_off_rootll = (size_t)cur * K * N * 8;
@@ -852,9 +1022,9 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             }
             c->run.local_book = local_book;
             const int nbook = local_book ? Kl : K;
-            if (N <= 16 && !getenv("PHYLO_BOOK_ONE_PER_WAVE"))        // 4 particles per wave (PK_AUX + 2 = 10 <= 16 lanes)
+            if (N <= 16 && !c->env.book_one_per_wave)        // 4 particles per wave (PK_AUX + 2 = 10 <= 16 lanes)
                 hipLaunchKernelGGL(pk_rank_book_packed<16>, dim3(cdiv(nbook, 4)), dim3(64), lds * 4, c->stream, b);
-            else if (N <= 32 && !getenv("PHYLO_BOOK_ONE_PER_WAVE"))   // 2 particles per wave
+            else if (N <= 32 && !c->env.book_one_per_wave)   // 2 particles per wave
                 hipLaunchKernelGGL(pk_rank_book_packed<32>, dim3(cdiv(nbook, 2)), dim3(64), lds * 2, c->stream, b);
             else
                 hipLaunchKernelGGL(pk_rank_book, dim3(nbook), dim3(64), lds, c->stream, b);
@@ -872,7 +1042,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                 CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
             }
         }
-        const bool nostore = (b.lazy || b.no_store) && !getenv("PHYLO_MERGE_PAIR_FORM");   // row-per-thread form when nothing is stored
+        const bool nostore = (b.lazy || b.no_store) && !c->env.merge_pair_form;   // row-per-thread form when nothing is stored
         if (timek) {  // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
             if (nostore) hipExtLaunchKernelGGL(pk_rank_merge_nostore, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
             else hipExtLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
@@ -1000,6 +1170,10 @@ int phylo_sweep_finish(phylo_ctx* c) {
 }
 
 int phylo_sweep_async(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) {
+    if (!c) return fail(nullptr, PHYLO_EINVAL, "ctx is NULL");
+    int Wg = 0, m = 0;
+    if (persist_plan(c, flags, 1, &Wg, &m)) return sweep_persistent(c, seed, flags, nullptr, 1, Wg, m);
+    c->last_persistent = false;
     CHK(phylo_sweep_begin(c, seed, flags, M));
     for (int r = 0; r < c->N - 1; ++r) CHK(phylo_sweep_step(c));
     return phylo_sweep_finish(c);
@@ -1013,6 +1187,13 @@ int phylo_sweep_batch_begin(phylo_ctx* c, const uint64_t* seeds, int G, uint32_t
 }
 
 int phylo_sweep_batch_async(phylo_ctx* c, const uint64_t* seeds, int G, uint32_t flags) {
+    if (!c) return fail(nullptr, PHYLO_EINVAL, "ctx is NULL");
+    int Wg = 0, m = 0;
+    if (seeds && G >= 1 && G <= PK_MAX_GROUPS && c->K % G == 0 && persist_plan(c, flags, G, &Wg, &m)) {
+        c->h_group_seeds.assign(seeds, seeds + G);          // stays alive until the copy has run
+        return sweep_persistent(c, seeds[0], flags, c->h_group_seeds.data(), G, Wg, m);
+    }
+    c->last_persistent = false;
     CHK(phylo_sweep_batch_begin(c, seeds, G, flags));
     for (int r = 0; r < c->N - 1; ++r) CHK(phylo_sweep_step(c));
     return phylo_sweep_finish(c);
@@ -1047,7 +1228,7 @@ int phylo_sweep_fetch(phylo_ctx* c, double* log_weights, double* log_lik, double
         HIPCHK(c, hipMemcpy(&tmo, c->d_counter + 1, sizeof tmo, hipMemcpyDeviceToHost));
         if (tmo) {
             HIPCHK(c, hipMemset(c->d_counter + 1, 0, sizeof tmo));
-            return fail(c, PHYLO_EHIP, "scan -> bookkeeping hand-off timed out inside a launch; results are invalid");
+            return fail(c, PHYLO_EHIP, "a bounded wait between workgroups timed out inside a launch; results are invalid");
         }
     }
     // log_weights / log_lik are stored with global columns; hand back this rank's columns
@@ -1240,6 +1421,16 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         perf->sweep_ms = ms;
         perf->n_launches = 2 * R + 7;
     }
+    return PHYLO_OK;
+}
+
+int phylo_debug_stamps(phylo_ctx* c, uint64_t* out, int n) {
+    CHK(bind(c));
+    if (!c->d_stamps) return fail(c, PHYLO_ESTATE, "no stamps: create the context with PHYLO_PERSIST_STAMPS=1 and run a one-launch sweep");
+    const int have = c->N * PP_NSTAMP;
+    if (!out || n < have) return fail(c, PHYLO_EINVAL, "phylo_debug_stamps needs room for N * %d = %d values", PP_NSTAMP, have);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->d_stamps, (size_t)have * 8, hipMemcpyDeviceToHost));
     return PHYLO_OK;
 }
 

@@ -384,13 +384,15 @@ def test_fused_scan_bookkeeping_launch(primate, monkeypatch):
     Q = O.get_Q(O.init_y_q())
     a = make_ctx(primate, 200, Q)
     ra = a.sweep(9)
-    monkeypatch.setenv("PHYLO_FUSE_SCAN", "1")
+    a.close()
+    monkeypatch.setenv("PHYLO_FUSE_SCAN", "1")            # the switches are read when a context is created
+    b = make_ctx(primate, 200, Q)
     for seed in (9, 10, 11):
-        rb = a.sweep(seed)
+        rb = b.sweep(seed)
         if seed == 9:
             assert_bit_equal(ra['log_weights'], rb['log_weights'], "fused vs separate launches")
             np.testing.assert_array_equal(ra['ancestors'], rb['ancestors'])
-    a.close()
+    b.close()
 
 
 def test_lazy_nodes_equal_eager_nodes(monkeypatch):
