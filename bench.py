@@ -1,12 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py -- particle-site-likelihoods/sec of the CSMC sweep on MI355X (BASELINE.json metric).
+"""bench.py -- particle-site-likelihoods/sec + |delta log Z-hat| of the CSMC sweep on MI355X (BASELINE.json metric).
 
 A "step" is one full sweep (N-1 rank events: draws, transition matrices, resampling, Felsenstein
 merges, weights, log Z-hat) over the alignment already resident in HBM.  Default workload: primate.p
-(N=12, S=898), jcmodel=false initial Q (GTR-init), K=2048 particles per GPU.  Throughput form on one GPU:
-independent sweeps (own seed, own resampling, own log Z-hat, each bit-identical to the sweep run alone) are issued
-up to ten per set of launches (phylo_sweep_batch_async) on three contexts in flight; `single_sweep_ms` is the
-latency of one sweep alone.
+(N=12, S=898), jcmodel=false initial Q (GTR-init), K=2048 particles per GPU.
+
+What the line reports:
+  value / ms_per_step   whole-job throughput of the timed region: independent sweeps (own seed, own resampling, own log
+                        Z-hat, each bit-identical to the sweep run alone) issued up to ten per set of launches
+                        (phylo_sweep_batch_async) on three contexts in flight.  The K steps are timed `repeats` times
+                        (>= 100 ms in all) and the MEDIAN repetition is reported.
+  t_sweep_ms            device time of ONE sweep alone (hipEvents on its stream), median of >= 20 after 3 warm-ups: the
+                        reference's own usage (one evaluation sweep per epoch; training steps are sequential).
+  delta_logZ_max, ancestors_equal   seeds 0..9 at the bench's K against the C oracle (the |delta log Z-hat| half of the metric).
+  roofline              the dominant kernel (the Felsenstein merge) against the resource that binds it.  With lazy nodes the
+                        launch moves ~2 % of the 96 B/unit algorithmic bytes through HBM and is bound by fp64 VALU ISSUE:
+                        frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x launch duration), instruction count from the
+                        committed rocprofv3 --pmc run at this launch shape (profiles/r02_merge_pmc.json), duration measured
+                        live with kernel-stamped HIP events.  hbm_frac = counter bytes / duration / 8 TB/s.  alg_equiv_GBps
+                        (96 B x units / duration) is an algorithmic-equivalent rate, NOT an HBM fraction.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -31,6 +43,9 @@ from phylo_amd.datasets import load_dataset, synthetic_alignment  # noqa: E402
 from phylo_amd.rendezvous import exchange_comm_id  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+N_SIMD = 256 * 4           # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md)
+CLK_HZ = 2.4e9             # max clock; in-kernel s_memtime / s_memrealtime read 2.36-2.39 GHz on this workload (tools/persist_probe.py)
+VALU_ISSUE_CYCLES = 4      # a wave64 VALU instruction occupies its SIMD-32 for 4 cycles at fp64 / single-wave issue rate
 
 
 def parse():
@@ -51,6 +66,9 @@ def parse():
     p.add_argument('--twisting', action='store_true', help='twisted proposal (vncsmc.py); BASELINE config 2')
     p.add_argument('--M', type=int, default=1, help='sub-samples of the twisted proposal')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-parity', action='store_true', help='skip the 10-seed comparison with the C oracle')
+    p.add_argument('--min-timed-ms', type=float, default=100.0, help='repeat the K timed steps until this much time is covered')
+    p.add_argument('--one-launch', action='store_true', help='single sweeps (t_sweep) in the one-launch form (phylo_persist.h)')
     p.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline duration')
     return p.parse_args()
 
@@ -191,12 +209,20 @@ def main():
 
     run(n_streams * batch, a.seed + 2000)            # untimed: every context (and its pool's pages) touched once
     run(-(-max(a.warmup, 0) // batch) * batch, a.seed + 1000)   # W warm-up steps, rounded up to whole launch sets
-    ctx.comm_barrier()
-    t0 = time.perf_counter()
-    run(a.steps, a.seed)
-    ctx.comm_barrier()
-    dt = time.perf_counter() - t0
-    dt = ctx.comm_max(dt)                            # max over ranks
+    # the K steps, timed `repeats` times (each bracketed by the barrier; max over ranks), median reported: one repetition of
+    # the default K lasts a few ms, too short to quote alone
+    reps_dt = []
+    while True:
+        ctx.comm_barrier()
+        t0 = time.perf_counter()
+        run(a.steps, a.seed)
+        ctx.comm_barrier()
+        reps_dt.append(ctx.comm_max(time.perf_counter() - t0))      # max over ranks (every rank takes the same decision below)
+        if sum(reps_dt) * 1e3 >= a.min_timed_ms and len(reps_dt) >= 3:
+            break
+        if len(reps_dt) >= 400:
+            break
+    dt = float(np.median(reps_dt))
     if batch > 1:
         nb = a.steps // batch
         last = single.sweep_fetch(arrays=False) if a.steps % batch else ctxs[(nb - 1) % n_streams].sweep_fetch(arrays=False)
@@ -207,14 +233,35 @@ def main():
 
     # one sweep at a time on one stream (latency of a single sweep), and the dominant kernel (the
     # Felsenstein merge): average launch duration from HIP events on the ctx stream, nothing else in flight
-    for s in range(3):                              # untimed: this context's pages and caches
-        single.sweep_async(a.seed + 3000 + s, flags=sweep_flags, M=a.M)
+    single_flags = sweep_flags | (_ffi.ONE_LAUNCH if a.one_launch else 0)
+    for s in range(3):                              # 3 warm-ups
+        single.sweep_async(a.seed + 3000 + s, flags=single_flags, M=a.M)
     single.synchronize()
+    ev_ms = []
+    for s in range(24):                             # device time of each sweep alone: hipEvents on the context's stream
+        single.sweep_async(a.seed + s, flags=single_flags, M=a.M)
+        ev_ms.append(single.sweep_fetch(arrays=False)['stats']['sweep_ms'])
+    t_sweep_ms = float(np.median(ev_ms))
     t1 = time.perf_counter()
     for s in range(10):
-        single.sweep_async(a.seed + s, flags=sweep_flags, M=a.M)
+        single.sweep_async(a.seed + s, flags=single_flags, M=a.M)
     single.synchronize()
     single_ms = (time.perf_counter() - t1) / 10 * 1e3
+    # the |delta log Z-hat| half of the metric: seeds 0..9 at this K against the C oracle (identical draws by contract)
+    parity = None
+    if world == 1 and not a.no_parity and not a.no_cpu_baseline:
+        from oracle import c_oracle as CO
+        worst, same = 0.0, True
+        for sd in range(10):
+            single.sweep_async(sd, flags=single_flags, M=a.M)
+            out = single.sweep_fetch()
+            if a.twisting:
+                ref = CO.sweep_twisted(g, Q, pi, lam, lam, K_global, a.M, sd, jc=a.jcmodel)
+            else:
+                ref = CO.sweep(g, Q, pi, lam, lam, K_global, sd, jc=a.jcmodel)
+            worst = max(worst, abs(out['logZ'] - ref['logZ']))
+            same = same and bool(np.array_equal(out['ancestors'], ref['ancestors']))
+        parity = {"delta_logZ_max": worst, "ancestors_equal": same}
     prof_sweeps = 3
     merge_ms, merge_n = 0.0, 0
     for s in range(prof_sweeps):                    # the launch form of the timed region, one at a time, kernel-stamped events
@@ -230,16 +277,41 @@ def main():
     lazy_nodes = not a.twisting and not os.environ.get('PHYLO_EAGER_NODES')
     merge_kernel = "pk_rank_merge_nostore" if lazy_nodes else "pk_rank_merge"
     avg_s = merge_ms / merge_n * 1e-3
-    achieved = bytes_per_launch / avg_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tpath):
+    alg_equiv = bytes_per_launch / avg_s / 1e9
+    # counters of the committed rocprofv3 --pmc runs at THIS launch shape (they cannot be read inside the run)
+    pmc = None
+    for tpath in sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', 'r*_merge_pmc.json')), reverse=True):
         try:
-            tj = json.load(open(tpath))
-            if tj.get('workload') == wname and tj.get('K') == ctx.K_local and tj.get('kernel') == merge_kernel:
-                traffic = tj.get('hbm_bytes_per_launch')
+            for e in json.load(open(tpath)).get('launch_shapes', []):
+                if e.get('workload') == wname and e.get('particles_per_launch') == ctx.K_local and e.get('kernel') == merge_kernel:
+                    pmc = dict(e, source=os.path.basename(tpath))
+                    break
         except Exception:
-            traffic = None
+            pass
+        if pmc:
+            break
+    valu_peak = N_SIMD * CLK_HZ / VALU_ISSUE_CYCLES / 1e9          # G wave-instructions / s the chip can issue
+    if pmc and pmc.get('hbm_bytes_per_launch') is not None and pmc['hbm_bytes_per_launch'] / avg_s / 1e9 > 0.5 * HBM_PEAK_GBPS:
+        bound = "hbm"
+    else:
+        bound = "valu"
+    roof = {"kernel": merge_kernel, "avg_launch_us": avg_s * 1e6, "particles_per_launch": ctx.K_local,
+            "alg_bytes_per_launch": bytes_per_launch, "alg_equiv_GBps": alg_equiv,
+            "alg_equiv_note": "96 B x units / duration: an algorithmic-equivalent rate, not HBM traffic (lazy nodes store nothing; children are 1-byte codes or L2-resident)",
+            "traffic": None, "hbm_frac": None, "valu_frac": None, "pmc_source": pmc['source'] if pmc else None}
+    if pmc:
+        if pmc.get('hbm_bytes_per_launch') is not None:
+            roof["traffic"] = pmc['hbm_bytes_per_launch']
+            roof["hbm_GBps"] = pmc['hbm_bytes_per_launch'] / avg_s / 1e9
+            roof["hbm_frac"] = roof["hbm_GBps"] / HBM_PEAK_GBPS
+        if pmc.get('sq_insts_valu_per_launch') is not None:
+            roof["valu_Ginstr_per_s"] = pmc['sq_insts_valu_per_launch'] / avg_s / 1e9
+            roof["valu_frac"] = roof["valu_Ginstr_per_s"] / valu_peak
+    if bound == "hbm":
+        roof.update({"bound": "hbm", "achieved": roof.get("hbm_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": roof["hbm_frac"]})
+    else:
+        roof.update({"bound": "valu", "achieved": roof.get("valu_Ginstr_per_s"), "peak": valu_peak, "unit": "G wave-instr/s (fp64 VALU issue)",
+                     "frac": roof["valu_frac"]})
 
     if rank == 0:
         units_per_step = float(K_global) * S * (N - 1)
@@ -256,13 +328,19 @@ def main():
                        "parallelism": "particles sharded over %d GPU(s), global resampling" % world,
                        "sweeps_per_launch_set": batch, "contexts_in_flight": n_streams,
                        "sweeps_in_flight": n_streams * batch},
-            "single_sweep_ms": single_ms,
+            "timed_region": {"repeats": len(reps_dt), "ms_total": sum(reps_dt) * 1e3, "ms_per_step_min": min(reps_dt) / a.steps * 1e3,
+                             "ms_per_step_max": max(reps_dt) / a.steps * 1e3, "reported": "median repetition"},
+            "t_sweep_ms": t_sweep_ms,
+            "t_sweep": {"n": len(ev_ms), "min_ms": min(ev_ms), "max_ms": max(ev_ms), "timer": "hipEvents on the sweep's stream",
+                        "form": "one launch (phylo_persist.h)" if a.one_launch else "launches per rank event",
+                        "units_per_s": units_per_step / world / (t_sweep_ms * 1e-3),
+                        "alg_equiv_frac_of_8TBps": 96.0 * units_per_step / world / (t_sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "single_sweep_wall_ms": single_ms,
             "log_Z": last['logZ'],
-            "roofline": {"bound": "hbm", "kernel": merge_kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "alg_bytes_per_launch": bytes_per_launch, "avg_launch_us": avg_s * 1e6,
-                         "sweep_frac_of_peak": (96.0 * units_per_step / world) / (dt / a.steps) / 1e9 / HBM_PEAK_GBPS},
+            "roofline": roof,
         }
+        if parity is not None:
+            line.update(parity)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds, a.M if a.twisting else 0)
         print(json.dumps(line), flush=True)

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/:
-   profiles/<tag>_kernel_stats_{default,1stream}.csv  rocprofv3 --stats tables as produced
-   profiles/<tag>_summary.md                          per-kernel averages, HBM traffic of the merge kernel
-   profiles/pmc_traffic.json                          read by bench.py for roofline.traffic
+   profiles/<tag>_kernel_stats_<run>.csv   rocprofv3 --stats tables as produced
+   profiles/<tag>_merge_pmc.json           per launch shape of the merge kernels: SQ counters, FETCH_SIZE / WRITE_SIZE and the
+                                           HBM bytes derived from them (read by bench.py for its roofline block)
+   profiles/<tag>_summary.md               per-kernel averages and the roofline arithmetic, with the commands
+usage: python tools/summarize_profiles.py r02
 """
 import collections
 import csv
@@ -13,10 +15,12 @@ import shutil
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
+S_SITES, WORKLOAD = 898, "primate.p"
+N_SIMD, CLK, HBM = 1024, 2.4e9, 8.0e12
 
 
 def one(pattern):
@@ -24,87 +28,99 @@ def one(pattern):
     return f[-1] if f else None          # gpurun merges runs into the same directory: take the newest
 
 
+RUNS = [("default", "`python bench.py --steps 30 --warmup 3` (10 sweeps per launch set x 3 contexts in flight: the timed region of the bench line)"),
+        ("1ctx", "`--streams 1`: the same launch sets one at a time (the form whose merge launches bench.py prices)"),
+        ("1stream", "`--streams 1 --batch 1`: one sweep at a time, launches per rank event"),
+        ("onelaunch", "`--streams 1 --batch 1 --one-launch`: single sweeps (t_sweep section) in the one-launch form, phylo_persist.h"),
+        ("twist", "`--twisting --M 1 --streams 1`"), ("ds1", "`--dataset hohna_data_1 --n_particles 4096 --streams 1`"),
+        ("train", "`python tools/train_probe.py --steps 10` (sweep with the graph kept + reverse pass)")]
 lines = ["# rocprofv3 summary, round %s" % tag, "",
-         "Command: `python bench.py --steps 30 --warmup 3 --no-cpu-baseline` (primate.p N=12 S=898, GTR-init, K=2048;",
-         "default = 3 independent sweeps per set of launches (merge launches of 6144 particles) on 3 contexts in flight;",
-         "`1ctx` = `--streams 1`: the same launch sets one at a time -- the form whose merge launches `bench.py` times for `roofline`;",
-         "`1stream` = `--streams 1 --batch 1`, one sweep at a time (merge launches of 2048 particles); `twist` = `--twisting --M 1 --streams 1`;",
-         "`ds1` = `--dataset hohna_data_1 --n_particles 4096 --streams 1`; `train` = `python tools/train_probe.py --steps 10`:",
-         "VI training steps, sweep with the graph kept + reverse pass, pg_* kernels).  Raw tables: `%s_kernel_stats_*.csv`." % tag, ""]
-for name in ("default", "1ctx", "1stream", "twist", "ds1", "train"):
+         "Workload: primate.p N=12 S=898, GTR-init, K=2048 per sweep.  All bench commands carry",
+         "`--no-cpu-baseline --no-parity --min-timed-ms 0`.  Raw tables: `%s_kernel_stats_*.csv`; counters: `%s_merge_pmc.json`." % (tag, tag), ""]
+for name, what in RUNS:
     st = one("trace_%s/*/*_kernel_stats.csv" % name)
     if not st:
         continue
     shutil.copy(st, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, name)))
-    lines += ["## kernel stats (%s)" % name, "", "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
+    lines += ["## kernel stats: %s" % name, "", what, "", "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(st)):
         lines.append("| %s | %s | %.2f | %.2f | %.2f | %s |" % (r['Name'][:60], r['Calls'], float(r['AverageNs']) / 1e3,
                                                          float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
     tr = one("trace_%s/*/*_kernel_trace.csv" % name)
-    if tr:                                                 # the merge kernel by launch shape (bench.py also runs single sweeps)
+    if tr:                                                 # the merge kernels by launch shape
         shapes = collections.defaultdict(list)
         for r in csv.DictReader(open(tr)):
-            if r['Kernel_Name'].startswith('pk_rank_merge'):
-                shapes[int(r['Grid_Size_X']) // 256].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
-        if len(shapes) > 0:
-            lines += ["", "`pk_rank_merge` by launch shape: " + "; ".join(
-                "%d particles: %d launches, avg %.2f us" % (k, len(v), sum(v) / len(v)) for k, v in sorted(shapes.items()))]
-    log = open(os.path.join(src, "trace_%s.log" % name)).read()
+            if r['Kernel_Name'].startswith('pk_rank_merge') or r['Kernel_Name'].startswith('void pp_sweep'):
+                shapes[(r['Kernel_Name'].split('(')[0], int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']))].append(
+                    (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        if shapes:
+            lines += ["", "by launch shape: " + "; ".join(
+                "`%s` x %d workgroups: %d launches, avg %.2f us" % (k[0], k[1], len(v), sum(v) / len(v)) for k, v in sorted(shapes.items()))]
+    logp = os.path.join(src, "trace_%s.log" % name)
+    log = open(logp).read() if os.path.exists(logp) else ""
     js = [l for l in log.splitlines() if l.startswith('{"metric"')]
     if js:
         j = json.loads(js[-1])
-        lines += ["", "bench line under the profiler: value %.4g %s, ms_per_step %.4f" % (j['value'], j['unit'], j['ms_per_step']), ""]
+        lines += ["", "bench line under the profiler: value %.4g %s, ms_per_step %.4f, t_sweep_ms %.4f (%s)"
+                  % (j['value'], j['unit'], j['ms_per_step'], j.get('t_sweep_ms', float('nan')), j.get('t_sweep', {}).get('form', '')), ""]
     tj = [l for l in log.splitlines() if l.startswith('{"dataset"')]
     if tj:
         j = json.loads(tj[-1])
         lines += ["", "training step under the profiler: forward %.3f ms, reverse pass %.3f ms, step wall %.3f ms (K=%d, %d sites)"
                   % (j['forward_ms'], j['backward_ms'], j['step_wall_ms'], j['K'], j['sites']), ""]
 
-# particles per merge launch of the timed region of the profiled command (the bench also issues single sweeps)
-Kl = 2048
-try:
-    jl = [l for l in open(os.path.join(src, "pmc_fetch.log")).read().splitlines() if l.startswith('{"metric"')]
-    if jl:
-        Kl = int(round(json.loads(jl[-1])['roofline']['alg_bytes_per_launch'] / (96.0 * 898)))
-except Exception:
-    pass
-agg = {}
-for cn, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+# ---- counters of the merge kernels, by launch shape (particles per launch = workgroups)
+acc = collections.defaultdict(lambda: collections.defaultdict(list))       # (kernel, particles) -> counter -> values
+dur = collections.defaultdict(list)
+for d in ("pmc_sq", "pmc_fetch", "pmc_write"):
     f = one("%s/*/*_counter_collection.csv" % d)
     if not f:
         continue
-    per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if r['Counter_Name'] == cn:
+        name = r['Kernel_Name'].split('(')[0]
+        if not name.startswith('pk_rank_merge'):
+            continue
+        key = (name, int(r['Grid_Size']) // int(r['Workgroup_Size']))
+        acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
+    t = one("%s/*/*_kernel_trace.csv" % d)
+    if t and d == "pmc_sq":
+        for r in csv.DictReader(open(t)):
             name = r['Kernel_Name'].split('(')[0]
-            if name.startswith('pk_rank_merge') and int(r['Grid_Size']) != Kl * 256:
-                continue                                   # a merge launch of another shape (the single-sweep section)
-            per[name].append(float(r['Counter_Value']))
-    agg[cn] = {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
-if agg:
-    lines += ["## HBM traffic from PMC counters (separate passes; values in KB per dispatch as rocprofv3 reports them)", "",
-              "| kernel | FETCH_SIZE avg KB | WRITE_SIZE avg KB | dispatches |", "|---|---|---|---|"]
-    for k in sorted(set(agg.get("FETCH_SIZE", {})) | set(agg.get("WRITE_SIZE", {}))):
-        fz = agg.get("FETCH_SIZE", {}).get(k, (0.0, 0))
-        wz = agg.get("WRITE_SIZE", {}).get(k, (0.0, 0))
-        lines.append("| %s | %.1f | %.1f | %d |" % (k, fz[0], wz[0], max(fz[1], wz[1])))
-    # the merge kernel of the timed region: the row-per-thread form when nothing is stored (lazy nodes), else the pair form
-    mk = "pk_rank_merge_nostore" if agg.get("FETCH_SIZE", {}).get("pk_rank_merge_nostore", (0.0, 0))[1] >= \
-        agg.get("FETCH_SIZE", {}).get("pk_rank_merge", (0.0, 0))[1] else "pk_rank_merge"
-    fz = agg.get("FETCH_SIZE", {}).get(mk, (0.0, 0))[0]
-    wz = agg.get("WRITE_SIZE", {}).get(mk, (0.0, 0))[0]
-    hbm = (2.0 * fz + wz) * 1024.0
-    alg = 96.0 * Kl * 898
-    lines += ["", "Merge kernel (`%s`), per launch:" % mk + " FETCH_SIZE %.0f KB is doubled (MI355X_MICROARCH.md, HBM: on gfx950" % fz,
-              "FETCH_SIZE reports half the bytes of a 16 B/lane coalesced stream), WRITE_SIZE %.0f KB is exact for 16 B/lane" % wz,
-              "streaming stores: HBM traffic = 2 x FETCH + WRITE = **%.1f MB** against **%.1f MB** algorithmic (96 B x %d particles x S)." % (hbm / 1e6, alg / 1e6, Kl),
-              "The children are leaves (L2-resident, 345 KB) or nodes of the few ancestors that survive resampling, so almost all",
-              "reads are served on chip." + (" The launch stores no nodes (lazy nodes, the default on one GPU): only the nodes whose creator"
-              " is adopted at the next resampling are written, by `pk_materialize_adopted` (its line above); the %.1f MB of"
-              " node stores per launch of the eager form are gone." % (32.0 * Kl * 898 / 1e6) if wz * 1024 < 0.1 * 32.0 * Kl * 898 else
-              " The kernel's HBM stream is the store of the new nodes (32 B x particles x S = %.1f MB)." % (32.0 * Kl * 898 / 1e6)), ""]
-    json.dump({"workload": "primate.p", "K": Kl, "kernel": mk, "hbm_bytes_per_launch": hbm,
-               "fetch_size_kb": fz, "write_size_kb": wz, "correction": "2*FETCH_SIZE + WRITE_SIZE (KB -> bytes x1024)",
-               "round": tag}, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+            if name.startswith('pk_rank_merge'):
+                dur[(name, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']))].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+shapes_out = []
+if acc:
+    lines += ["## counters of the merge kernel, per launch (three separate rocprofv3 --pmc passes of the `1ctx` command)", "",
+              "FETCH_SIZE / WRITE_SIZE are in KB as rocprofv3 reports them; on gfx950 FETCH_SIZE reads half the bytes of a wide coalesced",
+              "stream (MI355X_MICROARCH.md, HBM), so HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- an upper bound here, where much",
+              "of the read side is 1-byte codes.  fp64 VALU issue fraction = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x duration);",
+              "the durations in this table are those of the COUNTER pass (serialised dispatches); bench.py uses its own live launch time.", "",
+              "| kernel | particles / launch | launches | SQ_INSTS_VALU | SQ_INSTS_SALU | SQ_INSTS_LDS | SQ_WAVES | VALU instr / wave | FETCH KB | WRITE KB | HBM MB | algorithmic MB | avg us (pmc pass) | VALU issue frac | HBM frac |",
+              "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for key in sorted(acc):
+        c = {k: sum(v) / len(v) for k, v in acc[key].items()}
+        n = max(len(v) for v in acc[key].values())
+        fz, wz = c.get('FETCH_SIZE'), c.get('WRITE_SIZE')
+        hbm = (2.0 * fz + wz) * 1024.0 if fz is not None and wz is not None else None
+        alg = 96.0 * key[1] * S_SITES
+        us = sum(dur[key]) / len(dur[key]) if dur.get(key) else None
+        valu = c.get('SQ_INSTS_VALU')
+        vf = valu * 4.0 / (N_SIMD * CLK * us * 1e-6) if valu and us else None
+        hf = hbm / (us * 1e-6) / HBM if hbm and us else None
+        lines.append("| %s | %d | %d | %s | %s | %s | %s | %s | %s | %s | %s | %.1f | %s | %s | %s |" % (
+            key[0], key[1], n, *("%.3g" % c[k] if k in c else "-" for k in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_WAVES')),
+            "%.0f" % (valu / c['SQ_WAVES']) if valu and c.get('SQ_WAVES') else "-",
+            "%.0f" % fz if fz is not None else "-", "%.0f" % wz if wz is not None else "-", "%.1f" % (hbm / 1e6) if hbm else "-", alg / 1e6,
+            "%.2f" % us if us else "-", "%.3f" % vf if vf else "-", "%.4f" % hf if hf else "-"))
+        shapes_out.append({"workload": WORKLOAD, "kernel": key[0], "particles_per_launch": key[1], "launches": n,
+                           "sq_insts_valu_per_launch": valu, "sq_insts_salu_per_launch": c.get('SQ_INSTS_SALU'),
+                           "sq_insts_lds_per_launch": c.get('SQ_INSTS_LDS'), "sq_waves_per_launch": c.get('SQ_WAVES'),
+                           "sq_wave_cycles_per_launch": c.get('SQ_WAVE_CYCLES'), "sq_wait_any_per_launch": c.get('SQ_WAIT_ANY'),
+                           "fetch_size_kb": fz, "write_size_kb": wz, "hbm_bytes_per_launch": hbm,
+                           "correction": "2*FETCH_SIZE + WRITE_SIZE (KB -> bytes x1024), MI355X_MICROARCH.md HBM section",
+                           "alg_bytes_per_launch": alg, "avg_us_in_pmc_pass": us})
+    json.dump({"round": tag, "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 10 --warmup 10 "
+               "--streams 1 --no-cpu-baseline --no-parity --min-timed-ms 0 (three passes: SQ counters, FETCH_SIZE, WRITE_SIZE)",
+               "launch_shapes": shapes_out}, open(os.path.join(dst, "%s_merge_pmc.json" % tag), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
