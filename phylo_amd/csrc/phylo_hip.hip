@@ -341,6 +341,17 @@ int ensure_graph_state(phylo_ctx* c) {
     return PHYLO_OK;
 }
 
+// resampling scan of G groups of Kg log-weights: the LDS form when a group fits (phylo_persist.h), else pk_resample_scan
+int launch_scan(phylo_ctx* c, const double* logw, int Kg, int G, uint64_t* cdf, double* lse, int lse_stride) {
+    if (Kg <= PP_MAX_KG) {
+        hipLaunchKernelGGL(pp_resample_scan, dim3(G), dim3(512), pp_resample_scan_lds(Kg), c->stream, logw, Kg, cdf, lse, lse_stride);
+        return launch_check(c, "pp_resample_scan");
+    }
+    if (G > 1) hipLaunchKernelGGL(pk_resample_scan_groups, dim3(G), dim3(PK_COLS), pk_scan_lds_bytes(Kg), c->stream, logw, Kg, cdf, lse, lse_stride);
+    else hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(Kg), c->stream, logw, Kg, cdf, lse);
+    return launch_check(c, "pk_resample_scan");
+}
+
 // leaf node log-likelihoods sum_s log(pi . leaf[s]) (depend on pi and the leaves)
 int refresh_leaf_ll(phylo_ctx* c) {
     if (!(c->have_leaves && c->have_model && c->state_ready)) return PHYLO_OK;
@@ -639,9 +650,7 @@ int phylo_resample(phylo_ctx* c, const double* logw, int K, uint64_t seed, uint3
     CHK(scratch_get(c, 1, (size_t)K * 8, &dcdf));
     CHK(scratch_get(c, 2, (size_t)K * 8, &didx));
     HIPCHK(c, hipMemcpyAsync(dw, logw, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream, (const double*)dw, K,
-                       (uint64_t*)dcdf, (double*)nullptr);
-    CHK(launch_check(c, "pk_resample_scan"));
+    CHK(launch_scan(c, (const double*)dw, K, 1, (uint64_t*)dcdf, (double*)nullptr, 0));
     hipLaunchKernelGGL(pk_resample_search, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, (const uint64_t*)dcdf, K, K, 0, seed,
                        step, (int64_t*)didx);
     CHK(launch_check(c, "pk_resample_search"));
@@ -657,11 +666,7 @@ int phylo_log_zsmc(phylo_ctx* c, const double* logw, int R, int K, double* out) 
     CHK(scratch_get(c, 0, (size_t)(R ? R : 1) * K * 8, &dw));
     CHK(scratch_get(c, 1, (size_t)(R + 1) * 8, &dlse));
     if (R) HIPCHK(c, hipMemcpyAsync(dw, logw, (size_t)R * K * 8, hipMemcpyHostToDevice, c->stream));
-    for (int r = 0; r < R; ++r) {
-        hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream, (const double*)dw + (size_t)r * K, K,
-                           (uint64_t*)nullptr, (double*)dlse + r);
-        CHK(launch_check(c, "pk_resample_scan"));
-    }
+    for (int r = 0; r < R; ++r) CHK(launch_scan(c, (const double*)dw + (size_t)r * K, K, 1, (uint64_t*)nullptr, (double*)dlse + r, 0));
     hipLaunchKernelGGL(pk_logz_total, dim3(1), dim3(64), 0, c->stream, (const double*)dlse, R, (double*)dlse + R);
     CHK(launch_check(c, "pk_logz_total"));
     HIPCHK(c, hipMemcpyAsync(out, (double*)dlse + R, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1073,16 +1078,12 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                 }
             }
             if (G > 1) {                                       // one scan workgroup per batched sweep
-                hipLaunchKernelGGL(pk_resample_scan_groups, dim3(G), dim3(PK_COLS), pk_scan_lds_bytes(Kg), c->stream,
-                                   (const double*)(c->d_logw + (size_t)r * K), Kg, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
-                                   c->d_lse + r, R + 1);
-                CHK(launch_check(c, "pk_resample_scan_groups"));
+                CHK(launch_scan(c, (const double*)(c->d_logw + (size_t)r * K), Kg, G, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
+                                c->d_lse + r, R + 1));
                 ++launches;
             } else if (!fuse_scan || twist || r + 1 == R) {    // otherwise the next rank event's launch scans these weights
-                hipLaunchKernelGGL(pk_resample_scan, dim3(1), dim3(PK_COLS), pk_scan_lds_bytes(K), c->stream,
-                                   (const double*)(c->d_logw + (size_t)r * K), K, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
-                                   c->d_lse + r);
-                CHK(launch_check(c, "pk_resample_scan"));
+                CHK(launch_scan(c, (const double*)(c->d_logw + (size_t)r * K), K, 1, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
+                                c->d_lse + r, 0));
                 ++launches;
             }
         }

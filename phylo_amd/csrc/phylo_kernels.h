@@ -1306,6 +1306,29 @@ __global__ __launch_bounds__(64) void pk_twist_draws(const pk_twist_args ta, con
 }
 
 // one (pair, sub-sample) row of potentials for my canonical column: sites tid, tid + 256, ...
+// Two coded leaves: the site likelihood pi . ((leaf_cl P_l) o (leaf_cr P_r)) takes one of 25 values; lik25[cl * 5 + cr] holds
+// them, each computed once by exactly the per-site operations (pk_build_lik25), so a site is one lookup: same bits.
+__device__ __forceinline__ void pk_build_lik25(const double (*tabL)[4], const double (*tabR)[4], const double* pi4, double* lik25, int t) {
+    if (t < 25) {
+        const int cl = t / 5, cr = t - cl * 5;
+        const double pi[4] = {pi4[0], pi4[1], pi4[2], pi4[3]};
+        double o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = tabL[cl][j] * tabR[cr][j];
+        lik25[t] = pk_site_lik(pi, o);
+    }
+}
+__device__ __forceinline__ void pk_coded_row(const pk_rank_args& a, const uint8_t* Lc, const uint8_t* Rc, const double* lik25, pm_lp& col) {
+    const int tid = threadIdx.x, S = a.S;
+    int cln = 0, crn = 0;
+    if (tid < S) { cln = Lc[tid]; crn = Rc[tid]; }
+    for (int s = tid; s < S; s += PK_COLS) {
+        const int cl = cln, cr = crn;
+        if (s + PK_COLS < S) { cln = Lc[s + PK_COLS]; crn = Rc[s + PK_COLS]; }
+        pm_lp_mul(col, lik25[cl * 5 + cr]);
+    }
+}
+
 template <bool CL, bool CR>
 __device__ __forceinline__ void pk_twist_row(const pk_rank_args& a, const double* Lp, const double* Rp, const uint8_t* Lc,
                                              const uint8_t* Rc, const double (&Pl)[16], const double (&Pr)[16],
@@ -1400,6 +1423,7 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_ran
     __shared__ double cols[PK_COLS];
     __shared__ double sh4[4];
     __shared__ __attribute__((aligned(16))) double tabL[5][4], tabR[5][4];
+    __shared__ double lik25[25];
     const int k = blockIdx.x, kg = a.k0 + k, tid = threadIdx.x;
     const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
     const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // workgroup-uniform
@@ -1416,10 +1440,14 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_ran
         else if (tid < 64) pk_build_leaf_table(Pu + 16, tabR, tid - 32);
         __syncthreads();
     }
+    if (codedL && codedR) {
+        pk_build_lik25(tabL, tabR, a.pi, lik25, tid);
+        __syncthreads();
+    }
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     pm_lp col = pm_lp_init();
     if (codedL) {
-        if (codedR) pk_twist_row<true, true>(a, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col);
+        if (codedR) pk_coded_row(a, Lc, Rc, lik25, col);
         else pk_twist_row<true, false>(a, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col);
     } else {
         if (codedR) pk_twist_row<false, true>(a, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col);
@@ -1734,6 +1762,7 @@ __global__ void pk_math_probe(int op, const double* __restrict__ x, const double
         case 0: v = pm_exp(x[i]); break;
         case 1: v = pm_log(x[i]); break;
         case 2: v = x[i] / y[i]; break;
+        case 4: v = pm_exp_nonpos(x[i]); break;
         default: v = pm_fma(x[i], y[i], x[i]); break;
     }
     out[i] = v;

@@ -85,6 +85,42 @@ PM_HD double pm_exp(double x) {
     return y2 * 9.33263618503218878990e-302;   // 2^-1000
 }
 
+// pm_exp restricted to x <= 0 (and not NaN) WITHOUT branches: the resampling scan exponentiates logw - max, eight values per
+// thread, and straight-line code lets the eight evaluations overlap.  Bit-identical to pm_exp on its domain:
+//   * k = 0 is the general reduction with t = 0 (x - 0*ln2HI = x, 0*ln2LO = 0, exactly);
+//   * pm_exp's k == 0 result 1 - ((r c)/(c - 2) - r) equals the general 1 - ((lo - (r c)/(2 - c)) - hi) with lo = 0, hi = r:
+//     (c - 2) = -(2 - c) exactly, so the quotient only changes sign, and 0 - q = -q bit for bit for q != 0 (q = 0 needs
+//     r = 0, i.e. the |x| < 2^-28 case, which returns 1 + x);
+//   * the result cases (tiny, underflow, normal and subnormal scaling) are selected at the end.
+// tests/test_gpu_parity.py compares it with pm_exp on a million arguments and the edge cases.
+PM_HD double pm_exp_nonpos(double x) {
+    const double u_threshold = -7.45133219101941108420e+02;
+    const double ln2HI = 6.93147180369123816490e-01;
+    const double ln2LO = 1.90821492927058770002e-10;
+    const double invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01;
+    const double P2 = -2.77777777770155933842e-03;
+    const double P3 = 6.61375632143793436117e-05;
+    const double P4 = -1.65339022054652515390e-06;
+    const double P5 = 4.13813679705723846039e-08;
+    const double ax = -x;
+    const double xc = x < -800.0 ? -800.0 : x;                     // keep the int conversion in range (result is 0 anyway)
+    const int k = ax > 0.34657359027997264 ? (int)(invln2 * xc + -0.5) : 0;
+    const double t = (double)k;
+    const double hi = xc - t * ln2HI;
+    const double lo = t * ln2LO;
+    const double r = hi - lo;
+    const double tt = r * r;
+    const double c = r - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    const double yn = pm_from_bits(pm_bits(y) + ((uint64_t)(int64_t)k << 52));
+    const double ys = pm_from_bits(pm_bits(y) + ((uint64_t)(int64_t)(k + 1000) << 52)) * 9.33263618503218878990e-302;
+    double res = k >= -1021 ? yn : ys;
+    res = ax < 3.7252902984619141e-09 ? 1.0 + x : res;
+    res = x < u_threshold ? 0.0 : res;
+    return res;
+}
+
 // ------------------------------------------------------------------------------------------------
 // log
 // ------------------------------------------------------------------------------------------------

@@ -58,12 +58,12 @@ __device__ __forceinline__ void pp_stamp(const pp_args& a, int r, int i) {
 
 // per-particle LDS slot: what part A (before the wait) leaves for part B + merge (after it); one wave owns a slot
 struct pp_slot {
-    double *aux, *P, *tab;           // aux[PK_AUX]; P[32] = {P_l, P_r}; tab[2][5][4] leaf lookup tables built from P
+    double *aux, *P, *tab, *lik25;   // aux[PK_AUX]; P[32] = {P_l, P_r}; tab[2][5][4] leaf lookup tables built from P; lik25: see pk_build_lik25
     uint32_t* key; int32_t *rank, *inv, *misc;   // key[n4]; rank[slot] (-1: merged); inv[rank] = slot; misc[0] = il, [1] = ir
 };
 __host__ __device__ inline size_t pp_slot_bytes(int N) {
     const size_t n4 = ((size_t)N + 3) & ~(size_t)3;
-    return (PK_AUX + 32 + 40) * 8 + (3 * n4 + 4) * 4;
+    return (PK_AUX + 32 + 40 + 26) * 8 + (3 * n4 + 4) * 4;
 }
 __device__ __forceinline__ pp_slot pp_carve(char* base, int N) {
     const size_t n4 = ((size_t)N + 3) & ~(size_t)3;
@@ -71,7 +71,8 @@ __device__ __forceinline__ pp_slot pp_carve(char* base, int N) {
     L.aux = (double*)base;
     L.P = L.aux + PK_AUX;
     L.tab = L.P + 32;
-    L.key = (uint32_t*)(L.tab + 40);
+    L.lik25 = L.tab + 40;
+    L.key = (uint32_t*)(L.lik25 + 26);
     L.rank = (int32_t*)(L.key + n4);
     L.inv = L.rank + n4;
     L.misc = L.inv + n4;
@@ -165,6 +166,41 @@ __device__ __forceinline__ double pp_wave_tree_sum(double v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// wave maximum by the same DPP steps (max is exact and commutative), wave-uniform result
+__device__ __forceinline__ double pp_wave_max(double v) {
+    double o;
+    o = pp_dpp<0xB1>(v); v = o > v ? o : v;
+    o = pp_dpp<0x4E>(v); v = o > v ? o : v;
+    o = pp_dpp<0x141>(v); v = o > v ? o : v;
+    o = pp_dpp<0x140>(v); v = o > v ? o : v;
+    const double r0 = pp_readlane(v, 0), r1 = pp_readlane(v, 16), r2 = pp_readlane(v, 32), r3 = pp_readlane(v, 48);
+    const double a = r1 > r0 ? r1 : r0, b = r3 > r2 ? r3 : r2;
+    return b > a ? b : a;
+}
+// inclusive prefix sum of one u64 per lane over the wave (integers: any association gives the same bits): row_shr 1, 2, 4,
+// 8 inside rows of 16 (lanes shifted in read 0), then the three row totals are added by lane reads
+template <int CTRL>
+__device__ __forceinline__ unsigned long long pp_dpp_shr_u64(unsigned long long v) {
+    int lo = (int)(unsigned int)v, hi = (int)(unsigned int)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ unsigned long long pp_readlane_u64(unsigned long long v, int l) {
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, l);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long pp_wave_incl_scan_u64(unsigned long long v, int lane) {
+    v += pp_dpp_shr_u64<0x111>(v);    // row_shr:1
+    v += pp_dpp_shr_u64<0x112>(v);    // row_shr:2
+    v += pp_dpp_shr_u64<0x114>(v);    // row_shr:4
+    v += pp_dpp_shr_u64<0x118>(v);    // row_shr:8
+    const unsigned long long t0 = pp_readlane_u64(v, 15), t1 = pp_readlane_u64(v, 31), t2 = pp_readlane_u64(v, 47);
+    const int row = lane >> 4;
+    return v + (row > 0 ? t0 : 0ull) + (row > 1 ? t1 : 0ull) + (row > 2 ? t2 : 0ull);
+}
+
 // arrival: every handed-off byte was stored write-through (sc1); every wave drains, the workgroup meets, ONE lane adds
 __device__ __forceinline__ void pp_arrive(unsigned long long* ctr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -217,11 +253,7 @@ __device__ __forceinline__ void pp_scan(const double* logw, int Kg, unsigned lon
             if (!pm_isnan(v[j]) && v[j] > m) m = v[j];
         }
     }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double o = __shfl_xor(m, off, 64);
-        m = o > m ? o : m;
-    }
+    m = pp_wave_max(m);
     if (lane == 0) sh->d[wv] = m;
     __syncthreads();
     m = sh->d[0];
@@ -236,10 +268,18 @@ __device__ __forceinline__ void pp_scan(const double* logw, int Kg, unsigned lon
                 v[j] = pp_gld(logw + (k < Kg ? k : Kg - 1));
             }
         }
+        // w = exp(logw - max), straight-line (pm_exp_nonpos == pm_exp for arguments <= 0): the E evaluations overlap
+        double w[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const bool nan = pm_isnan(v[j]);
+            const double e = pm_exp_nonpos(nan ? 0.0 : v[j] - m);
+            w[j] = all_bad ? 1.0 : (nan ? 0.0 : e);
+        }
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const int k = base + tid + NT * j;
-            if (k < Kg) cdf[k] = pm_bits(all_bad ? 1.0 : (pm_isnan(v[j]) ? 0.0 : pp_exp(v[j] - m)));
+            if (k < Kg) cdf[k] = pm_bits(w[j]);
         }
     }
     __syncthreads();
@@ -266,12 +306,7 @@ __device__ __forceinline__ void pp_scan(const double* logw, int Kg, unsigned lon
 #pragma unroll
         for (int j = 1; j < E; ++j) e[j] += e[j - 1];
         const unsigned long long local = e[E - 1];
-        unsigned long long incl = local;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long o = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += o;
-        }
+        const unsigned long long incl = pp_wave_incl_scan_u64(local, lane);
         if (base > 0) __syncthreads();                 // the previous tile's wave totals have been read
         if (lane == 63) sh->u[wv] = incl;
         __syncthreads();
@@ -287,6 +322,21 @@ __device__ __forceinline__ void pp_scan(const double* logw, int Kg, unsigned lon
         carry += all;
     }
 }
+
+// The same scan as a launch of its own (launches-per-rank-event path, phylo_resample, phylo_log_zsmc): one workgroup of 512
+// threads per group, cdf built in LDS and copied out.  Replaces pk_resample_scan(_groups) whenever the group fits LDS.
+__global__ __launch_bounds__(512) void pp_resample_scan(const double* logw, int Kg, uint64_t* __restrict__ cdf, double* lse_out, int lse_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    pp_scan_lds* sh = reinterpret_cast<pp_scan_lds*>(smem);
+    unsigned long long* lcdf = reinterpret_cast<unsigned long long*>(smem + ((sizeof(pp_scan_lds) + 15) & ~(size_t)15));
+    const int g = blockIdx.x;
+    pp_scan<512>(logw + (size_t)g * Kg, Kg, lcdf, lse_out ? lse_out + (size_t)g * lse_stride : (double*)nullptr, sh, cdf != nullptr);
+    if (!cdf) return;
+    __syncthreads();
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(cdf) + (size_t)g * Kg;
+    for (int k = threadIdx.x; k < Kg; k += 512) out[k] = lcdf[k];
+}
+__host__ inline size_t pp_resample_scan_lds(int Kg) { return ((sizeof(pp_scan_lds) + 15) & ~(size_t)15) + (size_t)Kg * 8; }
 
 // ---- part A of a particle's rank event, by ONE wave, BEFORE the wait (nothing here depends on the resampling): the pair
 //      pick of extend_partial_state (vcsmc.py:303-305: Gumbel top-2 restated on the keys, remaining slots by ascending key),
@@ -337,6 +387,8 @@ __device__ __forceinline__ void pp_part_a(const pp_args& a, int r, int kg, uint3
     }
     if (lane < 20) pk_build_leaf_table(L.P, reinterpret_cast<double (*)[4]>(L.tab), lane);
     else if (lane >= 32 && lane < 52) pk_build_leaf_table(L.P + 16, reinterpret_cast<double (*)[4]>(L.tab + 20), lane - 32);
+    pp_lds_fence();
+    pk_build_lik25(reinterpret_cast<const double (*)[4]>(L.tab), reinterpret_cast<const double (*)[4]>(L.tab + 20), a.pi, L.lik25, lane);
     double lp = 0.0, rp = 0.0;                            // history rows 0..r with THIS rank's rate (quirk Q3)
     #pragma unroll 1
     for (int j = 0; j <= r; ++j) {
@@ -380,12 +432,18 @@ __device__ __forceinline__ void pp_blk_load(pp_blk<CL, CR, BS>& b, int S, int it
 }
 template <bool CL, bool CR, int BS, int C0>
 __device__ __forceinline__ void pp_blk_compute(const pp_blk<CL, CR, BS>& b, int S, int it0, const double (&Pl)[16], const double (&Pr)[16],
-                                               const double (*tabL)[4], const double (*tabR)[4], const double (&pi)[4], pm_lp (&col)[4],
-                                               bool& special, int lane) {
+                                               const double (*tabL)[4], const double (*tabR)[4], const double* lik25,
+                                               const double (&pi)[4], pm_lp (&col)[4], bool& special, int lane) {
 #pragma unroll
     for (int u = 0; u < BS; ++u) {
         const int s = lane + 64 * (it0 + u);
-        {
+        if constexpr (CL && CR) {                       // two coded leaves: one of 25 memoised site likelihoods
+            double lik = lik25[b.cl[u] * 5 + b.cr[u]];
+            lik = s < S ? lik : 1.0;
+            const bool sp = pp_lp_special(lik);
+            special |= sp;
+            pp_lp_mul_fast(col[(C0 + u) & 3], sp ? 1.0 : lik);
+        } else {
             double lpv[4], rpv[4], o[4];
             if constexpr (CL) {
                 const pk_d2 x = *reinterpret_cast<const pk_d2*>(&tabL[b.cl[u]][0]), y = *reinterpret_cast<const pk_d2*>(&tabL[b.cl[u]][2]);
@@ -428,7 +486,8 @@ __device__ __forceinline__ void pp_blk_compute(const pp_blk<CL, CR, BS>& b, int 
 template <bool CL, bool CR, int BS>
 __device__ __forceinline__ bool pp_merge_wave(int S, const double* Lp, const double* Rp, const uint8_t* Lc, const uint8_t* Rc,
                                               const double (&Pl)[16], const double (&Pr)[16], const double (*tabL)[4],
-                                              const double (*tabR)[4], const double (&pi)[4], pm_lp (&col)[4], int lane) {
+                                              const double (*tabR)[4], const double* lik25, const double (&pi)[4], pm_lp (&col)[4],
+                                              int lane) {
     const int nit = (S + 63) >> 6;
     bool special = false;
     pp_blk<CL, CR, BS> A, B;                               // BS = 4: each block covers columns 0..3; BS = 2: A columns 0,1, B columns 2,3
@@ -436,9 +495,9 @@ __device__ __forceinline__ bool pp_merge_wave(int S, const double* Lp, const dou
     #pragma unroll 1
     for (int it0 = 0; it0 < nit; it0 += 2 * BS) {
         pp_blk_load<CL, CR, BS>(B, S, it0 + BS, Lp, Rp, Lc, Rc, lane);
-        pp_blk_compute<CL, CR, BS, 0>(A, S, it0, Pl, Pr, tabL, tabR, pi, col, special, lane);
+        pp_blk_compute<CL, CR, BS, 0>(A, S, it0, Pl, Pr, tabL, tabR, lik25, pi, col, special, lane);
         pp_blk_load<CL, CR, BS>(A, S, it0 + 2 * BS, Lp, Rp, Lc, Rc, lane);
-        pp_blk_compute<CL, CR, BS, BS>(B, S, it0 + BS, Pl, Pr, tabL, tabR, pi, col, special, lane);
+        pp_blk_compute<CL, CR, BS, BS>(B, S, it0 + BS, Pl, Pr, tabL, tabR, lik25, pi, col, special, lane);
     }
     return special;
 }
@@ -557,11 +616,11 @@ __device__ __forceinline__ void pp_part_b_merge(const pp_args& a, int r, int kg,
     pm_lp col[4] = {pm_lp_init(), pm_lp_init(), pm_lp_init(), pm_lp_init()};
     bool special;
     if (codedL) {
-        if (codedR) special = pp_merge_wave<true, true, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col, lane);
-        else special = pp_merge_wave<true, false, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col, lane);
+        if (codedR) special = pp_merge_wave<true, true, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
+        else special = pp_merge_wave<true, false, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
     } else {
-        if (codedR) special = pp_merge_wave<false, true, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col, lane);
-        else special = pp_merge_wave<false, false, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col, lane);
+        if (codedR) special = pp_merge_wave<false, true, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
+        else special = pp_merge_wave<false, false, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
     }
     double g[4];
     if (__any(special)) {                                  // rare: redo the particle with the contract's rare branch in place

@@ -58,6 +58,12 @@ def test_device_arithmetic_contract(small):
     x = np.concatenate([np.exp(rng.uniform(-744, 709, 100000)), rng.uniform(0.5, 2, 50000),
                         [0.0, 1.0, 5e-324, 2.2e-308, np.inf, -1.0]])
     assert_bit_equal(ctx.math_probe(1, x), CO.math_probe(1, x), "log")
+    # the branch-free exp of the scan (pm_exp_nonpos) equals pm_exp on its whole domain x <= 0
+    x = np.concatenate([-rng.uniform(0, 760, 600000), -np.exp(rng.uniform(-60, 7, 400000)),
+                        [0.0, -0.0, -5e-324, -2.2e-308, -3.7252902984619141e-09, -3.72529029846191e-09, -3.7252902984619145e-09,
+                         -0.34657359027997264, -0.3465735902799726, -0.3465735902799727, -708.3964185322641, -709.0, -744.44, -745.13,
+                         -745.1332191019411, -745.1332191019412, -745.2, -800.0, -1e300, -np.inf]])
+    assert_bit_equal(ctx.math_probe(4, x), CO.math_probe(0, x), "exp for non-positive arguments")
     a, b = rng.normal(size=200000) * 10.0 ** rng.integers(-200, 200, 200000), rng.normal(size=200000)
     assert_bit_equal(ctx.math_probe(2, a, b), CO.math_probe(2, a, b), "div")
     assert_bit_equal(ctx.math_probe(3, a, b), CO.math_probe(3, a, b), "fma")
