@@ -57,6 +57,10 @@ def parse():
     p.add_argument('--n_particles', type=int, default=2048, help='particles PER GPU')
     p.add_argument('--jcmodel', default=False, type=lambda x: str(x).lower() == 'true')
     p.add_argument('--synthetic', default=None, help='N,S : synthetic iid-uniform alignment instead of --dataset')
+    p.add_argument('--flat', action='store_true',
+                   help='replace every row of the alignment by a gap row [1,1,1,1]: near-uniform weights under JC69, children spread over '
+                        'all earlier nodes (tools/regime_probe.py); the opposite extreme of real data')
+    p.add_argument('--eager', action='store_true', help='store every node (PHYLO_EAGER_NODES) instead of lazy nodes')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--streams', type=int, default=0,
                    help='independent sweeps kept in flight on separate HIP streams (0 = 3 on one GPU, 1 when sharded)')
@@ -65,6 +69,8 @@ def parse():
                         'up to 10 (plain proposal, small nodes), 1 otherwise')
     p.add_argument('--twisting', action='store_true', help='twisted proposal (vncsmc.py); BASELINE config 2')
     p.add_argument('--M', type=int, default=1, help='sub-samples of the twisted proposal')
+    p.add_argument('--params', default=None, help='.npz with Q, pi, lam_l, lam_r (e.g. trained parameters from tools/regime_probe.py) '
+                                                  'instead of the untrained model')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true', help='skip the 10-seed comparison with the C oracle')
     p.add_argument('--min-timed-ms', type=float, default=100.0, help='repeat the K timed steps until this much time is covered')
@@ -73,7 +79,7 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(g, Q, pi, lam, jc, K_gpu, seconds, twist_M=0):
+def cpu_baseline(g, Q, pi, lam, jc, K_gpu, seconds, twist_M=0, lam_r=None):
     """The C oracle (reference dataflow, OpenMP) timed on this host's cores on a bounded sample."""
     from oracle import c_oracle as CO
     N, S, _ = g.shape
@@ -84,11 +90,13 @@ def cpu_baseline(g, Q, pi, lam, jc, K_gpu, seconds, twist_M=0):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, int(os.environ.get('PHYLO_CPU_THREADS', '16'))))
     CO.set_threads(cores)
+    lam_r = lam if lam_r is None else lam_r
+
     def one(K, seed):
         if twist_M:
-            CO.sweep_twisted(g, Q, pi, lam, lam, K, twist_M, seed, jc=jc)
+            CO.sweep_twisted(g, Q, pi, lam, lam_r, K, twist_M, seed, jc=jc)
         else:
-            CO.sweep(g, Q, pi, lam, lam, K, seed, jc=jc)
+            CO.sweep(g, Q, pi, lam, lam_r, K, seed, jc=jc)
 
     t0 = time.perf_counter()
     one(64, 0)
@@ -124,10 +132,17 @@ def main():
         d = load_dataset(a.dataset)
         wname = {'primate_data': 'primate.p', 'primate_data_wang': 'primates_small.p'}.get(a.dataset, a.dataset)
     g = d['genome']
+    if a.flat:
+        g = np.ones_like(g)
+        wname += " shape, all-gap rows"
     N, S, _ = g.shape
     Q = M.jc_Q() if a.jcmodel else M.get_Q(M.init_y_q())
     pi = M.get_stationary_probs(np.zeros(4) + 0.25)
     lam = np.full(N - 1, 10.0)                       # branch_prior = log 10 (runner.py:38-41)
+    lam_r = lam
+    if a.params:
+        pz = np.load(a.params)
+        Q, pi, lam, lam_r = pz['Q'], pz['pi'], pz['lam_l'], pz['lam_r']
     K_global = a.n_particles * world
 
     ndev = _ffi.device_count()
@@ -149,7 +164,7 @@ def main():
     for i in range(n_streams):
         c = _ffi.Context(K_global * batch, N, S, device=local_rank % ndev)
         c.set_leaves(g)
-        c.set_model(Q, pi, lam, lam, jc69_closed_form=a.jcmodel)
+        c.set_model(Q, pi, lam, lam_r, jc69_closed_form=a.jcmodel)
         ctxs.append(c)
     ctx = ctxs[0]
     sharded = world > 1 or bool(os.environ.get('PHYLO_COMM_FORCE_RCCL'))   # the env: rehearse the sharded loop on one rank
@@ -159,12 +174,12 @@ def main():
         for c in ctxs[1:]:                            # further sweeps in flight: same communicator, one comm stream
             c.comm_share(ctx)
 
-    sweep_flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if a.twisting else 0)
+    sweep_flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if a.twisting else 0) | (_ffi.EAGER_NODES if a.eager else 0)
     single = ctx
     if batch > 1:                                     # one K-particle context: remainder sweeps, single-sweep latency
         single = _ffi.Context(K_global, N, S, device=local_rank % ndev)
         single.set_leaves(g)
-        single.set_model(Q, pi, lam, lam, jc69_closed_form=a.jcmodel)
+        single.set_model(Q, pi, lam, lam_r, jc69_closed_form=a.jcmodel)
         if sharded:
             single.comm_share(ctx)
 
@@ -256,9 +271,9 @@ def main():
             single.sweep_async(sd, flags=single_flags, M=a.M)
             out = single.sweep_fetch()
             if a.twisting:
-                ref = CO.sweep_twisted(g, Q, pi, lam, lam, K_global, a.M, sd, jc=a.jcmodel)
+                ref = CO.sweep_twisted(g, Q, pi, lam, lam_r, K_global, a.M, sd, jc=a.jcmodel)
             else:
-                ref = CO.sweep(g, Q, pi, lam, lam, K_global, sd, jc=a.jcmodel)
+                ref = CO.sweep(g, Q, pi, lam, lam_r, K_global, sd, jc=a.jcmodel)
             worst = max(worst, abs(out['logZ'] - ref['logZ']))
             same = same and bool(np.array_equal(out['ancestors'], ref['ancestors']))
         parity = {"delta_logZ_max": worst, "ancestors_equal": same}
@@ -274,7 +289,7 @@ def main():
         merge_n += st['merge_launches']
     bytes_per_launch = 96.0 * ctx.K_local * S       # 2 child reads + 1 parent write, 32 B each, per (particle, site)
     # lazy nodes (plain proposal): the launch stores nothing and runs the row-per-thread form of the merge
-    lazy_nodes = not a.twisting and not os.environ.get('PHYLO_EAGER_NODES')
+    lazy_nodes = not a.twisting and not a.eager and not os.environ.get('PHYLO_EAGER_NODES')
     merge_kernel = "pk_rank_merge_nostore" if lazy_nodes else "pk_rank_merge"
     avg_s = merge_ms / merge_n * 1e-3
     alg_equiv = bytes_per_launch / avg_s / 1e9
@@ -321,7 +336,7 @@ def main():
             "metric": "particle-site-likelihoods/sec", "value": units_per_step * a.steps / dt,
             "unit": "particle-site-likelihoods/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if a.synthetic else "primate.p alignment (real sites), untrained model parameters",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if a.synthetic else "primate.p alignment (real sites), %s model parameters" % ("trained (%s)" % os.path.basename(a.params) if a.params else "untrained"),
             "config": {"workload": "%s N=%d S=%d, %s, K=%d per GPU (K_total=%d), lambda=10, full sweep of %d rank events"
                                    % (wname, N, S, ("JC69" if a.jcmodel else "GTR-init (jcmodel=false)") + (" + twisting M=%d" % a.M if a.twisting else ""),
                                       a.n_particles, K_global, N - 1),
@@ -342,7 +357,7 @@ def main():
         if parity is not None:
             line.update(parity)
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds, a.M if a.twisting else 0)
+            line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds, a.M if a.twisting else 0, lam_r)
         print(json.dumps(line), flush=True)
     if single is not ctx:
         single.close()

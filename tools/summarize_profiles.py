@@ -17,7 +17,7 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-dst = os.path.join(ROOT, "profiles")
+dst = os.environ.get("PROFILES_OUT") or os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 S_SITES, WORKLOAD = 898, "primate.p"
 N_SIMD, CLK, HBM = 1024, 2.4e9, 8.0e12
