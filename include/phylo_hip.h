@@ -203,7 +203,6 @@ int phylo_comm_unique_id(char id[PHYLO_COMM_ID_BYTES]);
 /* Join `world` ranks.  The ctx must have been created with the GLOBAL K; afterwards this rank owns
  * particles [rank*K/world, (rank+1)*K/world) and sweep outputs are this shard's columns. */
 int phylo_comm_init(phylo_ctx* ctx, int rank, int world, const char id[PHYLO_COMM_ID_BYTES]);
-/* barrier + max over ranks of *value (RCCL all-reduce); identity when no comm is set. */
 /* A further context of this process joins `owner`'s communicator (same rank, same world) instead of creating its
  * own: all collectives of the process then run on one stream of one communicator, in host issue order.  Collective
  * (peer pools are mapped); every rank makes the call for its contexts in the same order.  `owner` must outlive ctx. */
@@ -211,6 +210,8 @@ int phylo_comm_share(phylo_ctx* ctx, phylo_ctx* owner);
 /* All-gather of a host blob of `bytes` bytes per rank (all = world * bytes, rank order): how a sharded caller
  * assembles per-particle outputs (ancestors, merges, branches) for host-side tree reconstruction. */
 int phylo_comm_allgather(phylo_ctx* ctx, const void* mine, size_t bytes, void* all);
+/* barrier + max over ranks of *value: an RCCL all-reduce (ncclMax) of one double on the communicator's stream (the
+ * host-mediated test transport gathers and takes the max on the host); identity when no communicator is set. */
 int phylo_comm_max(phylo_ctx* ctx, double* value);
 int phylo_comm_barrier(phylo_ctx* ctx);
 

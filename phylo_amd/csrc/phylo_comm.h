@@ -54,6 +54,8 @@ struct phylo_comm {
     phylo_comm* parent = nullptr;
     hipStream_t cstream = nullptr;     // owner only, created by the first phylo_comm_share
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    double* bounce = nullptr;          // owner only: device bounce buffer of the small host exchanges, grown on demand
+    size_t bounce_doubles = 0;
 };
 
 inline phylo_comm& phylo_comm_link(phylo_comm& c) { return c.parent ? *c.parent : c; }
@@ -117,6 +119,7 @@ inline void phylo_comm_destroy(phylo_comm* c) {
         return;
     }
     if (c->cstream) { (void)hipStreamDestroy(c->cstream); c->cstream = nullptr; }
+    if (c->bounce) { (void)hipFree(c->bounce); c->bounce = nullptr; c->bounce_doubles = 0; }
     if (c->nccl) { (void)ncclCommDestroy(c->nccl); c->nccl = nullptr; }
     if (c->shm) {
         munmap(c->shm, c->shm_bytes);
@@ -256,16 +259,30 @@ inline int phylo_comm_allgather_group(phylo_comm* const* comms, double* const* a
     return PHYLO_OK;
 }
 
-// all-gather of small host blobs (IPC handles) through a device bounce buffer
+// device bounce buffer of the communicator (allocated once, grown when a larger exchange comes)
+inline int phylo_comm_bounce(phylo_comm& link, size_t doubles, double** out, std::string* err) {
+    if (link.bounce_doubles < doubles) {
+        if (link.bounce) (void)hipFree(link.bounce);
+        link.bounce = nullptr;
+        link.bounce_doubles = 0;
+        const size_t want = doubles < 1024 ? 1024 : doubles;
+        if (hipMalloc((void**)&link.bounce, want * 8) != hipSuccess) return phylo_comm_fail(err, "hipMalloc", "bounce buffer");
+        link.bounce_doubles = want;
+    }
+    *out = link.bounce;
+    return PHYLO_OK;
+}
+
+// all-gather of small host blobs (IPC handles, per-particle outputs) through the communicator's device bounce buffer
 inline int phylo_comm_allgather_host(phylo_comm& c, const void* mine, size_t bytes, void* all, hipStream_t stream,
                                      std::string* err) {   // c may be a sharer: rank/world are mirrored, the link is resolved below
     if (c.transport == 0) { memcpy(all, mine, bytes); return PHYLO_OK; }
     const size_t count = (bytes + 7) / 8;
     double* d = nullptr;
-    if (hipMalloc((void**)&d, count * 8 * c.world) != hipSuccess) return phylo_comm_fail(err, "hipMalloc", "bounce buffer");
+    int rc = phylo_comm_bounce(phylo_comm_link(c), count * c.world, &d, err);
+    if (rc != PHYLO_OK) return rc;
     std::vector<double> tmp(count, 0.0);
     memcpy(tmp.data(), mine, bytes);
-    int rc = PHYLO_OK;
     if (hipMemcpy(d + (size_t)c.rank * count, tmp.data(), count * 8, hipMemcpyHostToDevice) != hipSuccess)
         rc = phylo_comm_fail(err, "hipMemcpy", "bounce H2D");
     double* arr[1] = {d};
@@ -276,7 +293,6 @@ inline int phylo_comm_allgather_host(phylo_comm& c, const void* mine, size_t byt
         rc = phylo_comm_fail(err, "hipMemcpy", "bounce D2H");
     if (rc == PHYLO_OK)
         for (int p = 0; p < c.world; ++p) memcpy((char*)all + (size_t)p * bytes, out.data() + (size_t)p * count, bytes);
-    (void)hipFree(d);
     return rc;
 }
 
@@ -333,11 +349,26 @@ inline int phylo_comm_map_extra(phylo_comm& c, void* mine_dev, std::vector<void*
     return PHYLO_OK;
 }
 
-// max over ranks of a host double (also a barrier)
-inline int phylo_comm_allreduce_max(phylo_comm& c, double* value, hipStream_t stream, std::string* err) {
-    if (c.transport == 0) return PHYLO_OK;
+// max over ranks of a host double (also a barrier).  RCCL: an all-reduce (ncclMax) of one device double on the
+// communicator's stream; host-mediated test transport: all-gather + host max.
+inline int phylo_comm_allreduce_max(phylo_comm& me, double* value, hipStream_t stream, std::string* err) {
+    if (me.transport == 0) return PHYLO_OK;
+    phylo_comm& c = phylo_comm_link(me);
+    if (c.transport == 1) {
+        double* d = nullptr;
+        int rc = phylo_comm_bounce(c, 2, &d, err);
+        if (rc != PHYLO_OK) return rc;
+        hipStream_t cs = c.cstream ? c.cstream : stream;
+        if (hipStreamSynchronize(stream) != hipSuccess) return phylo_comm_fail(err, "hipStreamSynchronize", "all-reduce");
+        if (hipMemcpyAsync(d, value, 8, hipMemcpyHostToDevice, cs) != hipSuccess) return phylo_comm_fail(err, "hipMemcpyAsync", "all-reduce in");
+        ncclResult_t r = ncclAllReduce(d, d + 1, 1, ncclDouble, ncclMax, c.nccl, cs);
+        if (r != ncclSuccess) return phylo_comm_fail(err, "ncclAllReduce", ncclGetErrorString(r));
+        if (hipMemcpyAsync(value, d + 1, 8, hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess)
+            return phylo_comm_fail(err, "hipMemcpyAsync", "all-reduce out");
+        return PHYLO_OK;
+    }
     std::vector<double> all(c.world);
-    int rc = phylo_comm_allgather_host(c, value, sizeof(double), all.data(), stream, err);
+    int rc = phylo_comm_allgather_host(me, value, sizeof(double), all.data(), stream, err);
     if (rc != PHYLO_OK) return rc;
     double m = all[0];
     for (int p = 1; p < c.world; ++p) m = all[p] > m ? all[p] : m;

@@ -343,8 +343,12 @@ int ensure_graph_state(phylo_ctx* c) {
 
 // resampling scan of G groups of Kg log-weights: the LDS form when a group fits (phylo_persist.h), else pk_resample_scan
 int launch_scan(phylo_ctx* c, const double* logw, int Kg, int G, uint64_t* cdf, double* lse, int lse_stride) {
-    if (Kg <= PP_MAX_KG) {
-        hipLaunchKernelGGL(pp_resample_scan, dim3(G), dim3(512), pp_resample_scan_lds(Kg), c->stream, logw, Kg, cdf, lse, lse_stride);
+    if (Kg <= 4096) {
+        hipLaunchKernelGGL(pp_resample_scan<512>, dim3(G), dim3(512), pp_resample_scan_lds(Kg), c->stream, logw, Kg, cdf, lse, lse_stride);
+        return launch_check(c, "pp_resample_scan");
+    }
+    if (Kg <= PP_SCAN_KERNEL_MAX_KG) {      // large groups (the replicated scan of a sharded sweep): 16 waves, 128 KiB of LDS
+        hipLaunchKernelGGL(pp_resample_scan<1024>, dim3(G), dim3(1024), pp_resample_scan_lds(Kg), c->stream, logw, Kg, cdf, lse, lse_stride);
         return launch_check(c, "pp_resample_scan");
     }
     if (G > 1) hipLaunchKernelGGL(pk_resample_scan_groups, dim3(G), dim3(PK_COLS), pk_scan_lds_bytes(Kg), c->stream, logw, Kg, cdf, lse, lse_stride);

@@ -78,7 +78,7 @@ __device__ __forceinline__ pp_slot pp_carve(char* base, int N) {
     L.misc = L.inv + n4;
     return L;
 }
-struct pp_scan_lds { double d[8]; unsigned long long u[8]; };
+struct pp_scan_lds { double d[16]; unsigned long long u[16]; };
 // LDS of one workgroup: scan scratch | ldf table | flags | own ancestors | adoption flags | particle slots | cdf
 struct pp_lds_layout { size_t ldf, flags, anc, adopted, slots, cdf, total; };
 __host__ __device__ inline pp_lds_layout pp_layout(int N, int m, int Kg) {
@@ -325,17 +325,19 @@ __device__ __forceinline__ void pp_scan(const double* logw, int Kg, unsigned lon
 
 // The same scan as a launch of its own (launches-per-rank-event path, phylo_resample, phylo_log_zsmc): one workgroup of 512
 // threads per group, cdf built in LDS and copied out.  Replaces pk_resample_scan(_groups) whenever the group fits LDS.
-__global__ __launch_bounds__(512) void pp_resample_scan(const double* logw, int Kg, uint64_t* __restrict__ cdf, double* lse_out, int lse_stride) {
+template <int NT>
+__global__ __launch_bounds__(NT) void pp_resample_scan(const double* logw, int Kg, uint64_t* __restrict__ cdf, double* lse_out, int lse_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     pp_scan_lds* sh = reinterpret_cast<pp_scan_lds*>(smem);
     unsigned long long* lcdf = reinterpret_cast<unsigned long long*>(smem + ((sizeof(pp_scan_lds) + 15) & ~(size_t)15));
     const int g = blockIdx.x;
-    pp_scan<512>(logw + (size_t)g * Kg, Kg, lcdf, lse_out ? lse_out + (size_t)g * lse_stride : (double*)nullptr, sh, cdf != nullptr);
+    pp_scan<NT>(logw + (size_t)g * Kg, Kg, lcdf, lse_out ? lse_out + (size_t)g * lse_stride : (double*)nullptr, sh, cdf != nullptr);
     if (!cdf) return;
     __syncthreads();
     unsigned long long* out = reinterpret_cast<unsigned long long*>(cdf) + (size_t)g * Kg;
-    for (int k = threadIdx.x; k < Kg; k += 512) out[k] = lcdf[k];
+    for (int k = threadIdx.x; k < Kg; k += NT) out[k] = lcdf[k];
 }
+#define PP_SCAN_KERNEL_MAX_KG 16384    // 128 KiB of cdf in LDS, 1024 threads: the replicated scan of 8 GPUs x 2048 particles
 __host__ inline size_t pp_resample_scan_lds(int Kg) { return ((sizeof(pp_scan_lds) + 15) & ~(size_t)15) + (size_t)Kg * 8; }
 
 // ---- part A of a particle's rank event, by ONE wave, BEFORE the wait (nothing here depends on the resampling): the pair

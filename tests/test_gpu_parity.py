@@ -140,7 +140,8 @@ def test_tree_loglik_golden_from_reference(golden_dir):
 def test_resample_bit_exact_and_edge_cases(small):
     ctx = make_ctx(small[:3, :16], 2, O.jc_Q())
     rng = np.random.default_rng(4)
-    for K in (1, 2, 255, 256, 1000, 2048, 5000):
+    # 4097, 12000, 16384: the 1024-thread LDS scan (128 KiB of cdf); 20000: beyond LDS, the global-memory scan
+    for K in (1, 2, 255, 256, 1000, 2048, 4096, 4097, 5000, 12000, 16384, 20000):
         for scale in (0.5, 30.0, 400.0):
             lw = rng.normal(scale=scale, size=K) - 6000.0
             idx = ctx.resample(lw, seed=11, step=3)
