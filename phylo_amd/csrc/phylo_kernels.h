@@ -1667,21 +1667,35 @@ __global__ __launch_bounds__(64) void pk_twist_choose(const pk_twist_args ta) {
         w[j] = all_bad ? 1.0 : (pm_isnan(v) ? 0.0 : pm_exp(v - mx));
     }
     __syncthreads();
-    if (lane != 0) return;
-    double ssum = 0.0;
-    uint64_t total = 0;
-    for (int j = 0; j < J; ++j) {
-        ssum = ssum + w[j];
-        total += all_bad ? 1ull : (uint64_t)(w[j] * PM_CDF_SCALE);
+    // integer CDF by the whole wave (integers: any order gives the same total and the same prefix sums): every lane sums the
+    // weights of its contiguous chunk, a shuffle scan gives the chunk offsets, the lane whose chunk crosses the threshold
+    // finds the index.  Only the floating-point sum of the normaliser keeps its contract order (increasing j, lane 0).
+    const int chunk = (J + 63) >> 6, j0 = lane * chunk, j1 = j0 + chunk < J ? j0 + chunk : J;
+    unsigned long long mine = 0;
+    for (int j = j0; j < j1; ++j) mine += all_bad ? 1ull : (unsigned long long)(w[j] * PM_CDF_SCALE);
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
     }
+    const uint64_t total = __shfl(incl, 63, 64);
     const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_TWIST, PK_TWIST_DRAW_BLOCK, a.seed);
     const uint64_t thr = pm_mulhi64(((uint64_t)x.y << 32) | x.x, total);
-    int jsel = J - 1;
-    uint64_t run = 0;
-    for (int j = 0; j < J; ++j) {
-        run += all_bad ? 1ull : (uint64_t)(w[j] * PM_CDF_SCALE);
-        if (run > thr) { jsel = j; break; }
+    int cand = J - 1;                                       // first j with (prefix sum through j) > thr, if it lies in my chunk
+    const bool crosses = incl > thr && incl - mine <= thr;
+    if (crosses) {
+        unsigned long long run = incl - mine;
+        for (int j = j0; j < j1; ++j) {
+            run += all_bad ? 1ull : (unsigned long long)(w[j] * PM_CDF_SCALE);
+            if (run > thr) { cand = j; break; }
+        }
     }
+    const unsigned long long who = __ballot(crosses);
+    const int jsel = who ? __shfl(cand, __ffsll((long long)who) - 1, 64) : J - 1;
+    if (lane != 0) return;
+    double ssum = 0.0;
+    for (int j = 0; j < J; ++j) ssum = ssum + w[j];
     const double logq = pot[jsel] - ((all_bad ? 0.0 : mx) + pm_log(ssum));
     const int t = jsel / M;
     int il = 0, rem = t;

@@ -122,5 +122,31 @@ if acc:
     json.dump({"round": tag, "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 10 --warmup 10 "
                "--streams 1 --no-cpu-baseline --no-parity --min-timed-ms 0 (three passes: SQ counters, FETCH_SIZE, WRITE_SIZE)",
                "launch_shapes": shapes_out}, open(os.path.join(dst, "%s_merge_pmc.json" % tag), "w"), indent=1)
+# ---- twisted proposal: SQ counters per kernel (durations from the un-countered trace_twist pass)
+f = one("pmc_twist/*/*_counter_collection.csv")
+if f:
+    tw = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        name = r['Kernel_Name'].split('(')[0]
+        if name.startswith('pk_twist') or name.startswith('pk_rank_merge'):
+            tw[name][r['Counter_Name']].append(float(r['Counter_Value']))
+    tdur = collections.defaultdict(list)
+    t = one("trace_twist/*/*_kernel_trace.csv")
+    if t:
+        for r in csv.DictReader(open(t)):
+            tdur[r['Kernel_Name'].split('(')[0]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    lines += ["## twisted proposal (M = 1, K = 2048): SQ counters per launch, averaged over the rank events", "",
+              "Contracts v3 / v4 in place (leaf x leaf rows priced by code pair, leaf x internal rows by code).  VALU issue fraction as above;",
+              "durations from the kernel-trace pass.", "",
+              "| kernel | launches | avg us | SQ_WAVES | SQ_INSTS_VALU | VALU / wave | SQ_INSTS_SALU | SQ_INSTS_LDS | wait share of wave cycles | VALU issue frac |",
+              "|---|---|---|---|---|---|---|---|---|---|"]
+    for name in sorted(tw):
+        c = {k: sum(v) / len(v) for k, v in tw[name].items()}
+        us = sum(tdur[name]) / len(tdur[name]) if tdur.get(name) else None
+        lines.append("| %s | %d | %s | %.3g | %.3g | %.0f | %.3g | %.3g | %.2f | %s |" % (
+            name, len(tw[name]['SQ_WAVES']), "%.2f" % us if us else "-", c['SQ_WAVES'], c['SQ_INSTS_VALU'], c['SQ_INSTS_VALU'] / max(c['SQ_WAVES'], 1),
+            c['SQ_INSTS_SALU'], c['SQ_INSTS_LDS'], c['SQ_WAIT_ANY'] / max(c['SQ_WAVE_CYCLES'], 1),
+            "%.3f" % (c['SQ_INSTS_VALU'] * 4.0 / (N_SIMD * CLK * us * 1e-6)) if us else "-"))
+    lines.append("")
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
