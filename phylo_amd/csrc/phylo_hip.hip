@@ -890,6 +890,7 @@ static int sweep_persistent(phylo_ctx* c, uint64_t seed, uint32_t flags, const u
     return PHYLO_OK;
 }
 
+
 int phylo_sweep_begin(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) { return sweep_begin_impl(c, seed, flags, M, nullptr, 1); }
 
 // Sharded lazy nodes, first half of a rank event: every rank marks the nodes adopted at this resampling (the search

@@ -344,6 +344,7 @@ __host__ inline size_t pp_resample_scan_lds(int Kg) { return ((sizeof(pp_scan_ld
 //      pick of extend_partial_state (vcsmc.py:303-305: Gumbel top-2 restated on the keys, remaining slots by ascending key),
 //      the branch-history priors with this rank's rate (quirk Q3, vcsmc.py:378-384), the proposal terms, and the particle's
 //      transition matrices + leaf lookup tables staged in LDS.  Same arithmetic and orders as pk_book_packed.
+template <bool STAGE>      // STAGE: also stage the particle's transition matrices, leaf tables and lik25 in the slot (one-launch sweep)
 __device__ __forceinline__ void pp_part_a(const pp_args& a, int r, int kg, uint32_t kin, uint64_t seed, const pp_slot& L, int lane,
                                           double lam_l, double lam_r, double loglam_l, double loglam_r) {
     const int N = a.N, n = N - r, K = a.K;
@@ -355,7 +356,7 @@ __device__ __forceinline__ void pp_part_a(const pp_args& a, int r, int kg, uint3
     }
     const double hbl = lane <= r ? pp_gld(a.bl + (size_t)lane * K + kg) : 0.0;     // rows 0..r of my branch history
     const double hbr = lane <= r ? pp_gld(a.br + (size_t)lane * K + kg) : 0.0;
-    if (lane < 32) L.P[lane] = pp_gld(a.Pmat + ((size_t)r * K + kg) * 32 + lane);
+    if constexpr (STAGE) { if (lane < 32) L.P[lane] = pp_gld(a.Pmat + ((size_t)r * K + kg) * 32 + lane); }
     pp_lds_fence();
     // largest key (lower slot on ties), then the second largest
     unsigned long long best = lane < n ? (((unsigned long long)L.key[lane] << 32) | (0xffffffffu - (uint32_t)lane)) : 0ull;
@@ -387,10 +388,12 @@ __device__ __forceinline__ void pp_part_a(const pp_args& a, int r, int kg, uint3
         }
         L.rank[lane] = rank;
     }
-    if (lane < 20) pk_build_leaf_table(L.P, reinterpret_cast<double (*)[4]>(L.tab), lane);
-    else if (lane >= 32 && lane < 52) pk_build_leaf_table(L.P + 16, reinterpret_cast<double (*)[4]>(L.tab + 20), lane - 32);
-    pp_lds_fence();
-    pk_build_lik25(reinterpret_cast<const double (*)[4]>(L.tab), reinterpret_cast<const double (*)[4]>(L.tab + 20), a.pi, L.lik25, lane);
+    if constexpr (STAGE) {
+        if (lane < 20) pk_build_leaf_table(L.P, reinterpret_cast<double (*)[4]>(L.tab), lane);
+        else if (lane >= 32 && lane < 52) pk_build_leaf_table(L.P + 16, reinterpret_cast<double (*)[4]>(L.tab + 20), lane - 32);
+        pp_lds_fence();
+        pk_build_lik25(reinterpret_cast<const double (*)[4]>(L.tab), reinterpret_cast<const double (*)[4]>(L.tab + 20), a.pi, L.lik25, lane);
+    }
     double lp = 0.0, rp = 0.0;                            // history rows 0..r with THIS rank's rate (quirk Q3)
     #pragma unroll 1
     for (int j = 0; j <= r; ++j) {
@@ -544,36 +547,45 @@ __device__ __forceinline__ const double* pp_node_ptr(const pp_args& a, int id) {
 // ---- part B + merge of one particle, by ONE wave, after the resampling: adoption of the ancestor's root table (the
 //      tf.gather of vcsmc.py:286-288 on integer tables), the new table (:361-373), the weight terms that depend on it
 //      (:376-392), the Felsenstein merge of the picked pair (:180-188) with its log-likelihood (:240-242), log w (:392).
-template <int BS>
-__device__ __forceinline__ void pp_part_b_merge(const pp_args& a, int r, int kg, int gbase, int anc, const pp_slot& L, const double* ldf,
-                                                const double (&pi)[4], double ll_tilde0, int lane) {
-    const int N = a.N, n = N - r, K = a.K, S = a.S, cur = r & 1, nxt = cur ^ 1;
-    // my lane's slot of the ancestor's table (tables of plane `cur` were stored write-through at rank event r-1)
+struct pp_b_out { int cl, cr; double sum_rem, fprior, logv, ll_tilde; };
+// WT: the next plane of the root tables is stored write-through (other workgroups of the SAME launch adopt it at the next
+// rank event: one-launch sweep); plain stores when a kernel boundary follows (two-launch rank event).
+template <bool WT>
+__device__ __forceinline__ pp_b_out pp_part_b(const pp_args& a, int r, int kg, int gbase, int anc, int il, int ir, const int32_t* inv,
+                                              const double* ldf, double ll_tilde0, int lane) {
+    const int N = a.N, n = N - r, K = a.K, cur = r & 1, nxt = cur ^ 1;
+    // my lane's slot of the ancestor's table
     const bool in = lane < n;
     const int node = in ? pp_gld(a.roots[cur] + (size_t)anc * N + lane) : 0;
     const int c = in ? pp_gld(a.cnt[cur] + (size_t)anc * N + lane) : 0;
     const double xll = in ? pp_gld(a.rootll[cur] + (size_t)anc * N + lane) : 0.0;
-    const double ll_tilde = (r > 0) ? pp_gld(a.ll + (size_t)(r - 1) * K + anc) : ll_tilde0;
-    pp_stamp(a, r, 8);
-    const int il = __builtin_amdgcn_readfirstlane(L.misc[0]), ir = __builtin_amdgcn_readfirstlane(L.misc[1]);
-    const int cl = __builtin_amdgcn_readlane(node, il), cr = __builtin_amdgcn_readlane(node, ir);
+    pp_b_out o;
+    o.ll_tilde = (r > 0) ? pp_gld(a.ll + (size_t)(r - 1) * K + anc) : ll_tilde0;
+    o.cl = __builtin_amdgcn_readlane(node, il);
+    o.cr = __builtin_amdgcn_readlane(node, ir);
     const int cnew = __builtin_amdgcn_readlane(c, il) + __builtin_amdgcn_readlane(c, ir);
     // the new table in position order: lane q < n-2 takes the slot whose rank is q, lane n-2 the node created now
-    const int src = lane < n - 2 ? L.inv[lane] : 0;
+    const int src = lane < n - 2 ? inv[lane] : 0;
     int onode = __shfl(node, src, 64), oc = __shfl(c, src, 64);
     const double oll = __shfl(xll, src, 64);
     if (lane == n - 2) { onode = N + r * K + kg; oc = cnew; }
     if (lane < n - 1) {
-        pp_st_i32(a.roots[nxt] + (size_t)kg * N + lane, onode);
-        pp_st_i32(a.cnt[nxt] + (size_t)kg * N + lane, oc);
-        if (lane < n - 2) pk_st_agent(a.rootll[nxt] + (size_t)kg * N + lane, oll);
+        if constexpr (WT) {
+            pp_st_i32(a.roots[nxt] + (size_t)kg * N + lane, onode);
+            pp_st_i32(a.cnt[nxt] + (size_t)kg * N + lane, oc);
+            if (lane < n - 2) pk_st_agent(a.rootll[nxt] + (size_t)kg * N + lane, oll);
+        } else {
+            a.roots[nxt][(size_t)kg * N + lane] = onode;
+            a.cnt[nxt][(size_t)kg * N + lane] = oc;
+            if (lane < n - 2) a.rootll[nxt][(size_t)kg * N + lane] = oll;
+        }
     }
     const double oldf = lane < n - 1 ? ldf[oc < N ? oc : N] : 0.0;
     if (lane == 0) {
         a.merges[((size_t)r * K + kg) * 2 + 0] = il;
         a.merges[((size_t)r * K + kg) * 2 + 1] = ir;
-        a.child[((size_t)r * K + kg) * 2 + 0] = cl;
-        a.child[((size_t)r * K + kg) * 2 + 1] = cr;
+        a.child[((size_t)r * K + kg) * 2 + 0] = o.cl;
+        a.child[((size_t)r * K + kg) * 2 + 1] = o.cr;
         if (r > 0) a.anc[(size_t)(r - 1) * K + kg] = anc - gbase;        // index inside the group
     }
     double sum_rem = 0.0, fprior = 0.0;                    // sequential sums in position order (values are wave-uniform)
@@ -586,7 +598,21 @@ __device__ __forceinline__ void pp_part_b_merge(const pp_args& a, int r, int kg,
         fprior = fprior + (-pp_readlane(oldf, p));
         vminus += cc - (cc == 1 ? 1 : 0);
     }
-    const double logv = pp_log((double)vminus);
+    o.sum_rem = sum_rem;
+    o.fprior = fprior;
+    o.logv = pp_log((double)vminus);
+    return o;
+}
+
+template <int BS>
+__device__ __forceinline__ void pp_part_b_merge(const pp_args& a, int r, int kg, int gbase, int anc, const pp_slot& L, const double* ldf,
+                                                const double (&pi)[4], double ll_tilde0, int lane) {
+    const int N = a.N, n = N - r, K = a.K, S = a.S, nxt = (r & 1) ^ 1;
+    pp_stamp(a, r, 8);
+    const int il = __builtin_amdgcn_readfirstlane(L.misc[0]), ir = __builtin_amdgcn_readfirstlane(L.misc[1]);
+    const pp_b_out b = pp_part_b<true>(a, r, kg, gbase, anc, il, ir, L.inv, ldf, ll_tilde0, lane);
+    const int cl = b.cl, cr = b.cr;
+    const double sum_rem = b.sum_rem, fprior = b.fprior, logv = b.logv, ll_tilde = b.ll_tilde;
     pp_stamp(a, r, 9);
     // a child created at the previous rank event is being written by its owner during THIS rank event
     const int fresh0 = N + (r - 1) * K;
@@ -731,7 +757,7 @@ __global__ __launch_bounds__(NT, NT / 256) void pp_sweep(const pp_args a) {
             // are still finishing the previous rank event
             if (r < R)
                 for (int p = wv; p < cnt; p += NW)
-                    pp_part_a(a, r, kb + c0 + p, (uint32_t)(kbl + c0 + p), seed, pp_carve(slots + (size_t)p * slot_stride, N), lane,
+                    pp_part_a<true>(a, r, kb + c0 + p, (uint32_t)(kbl + c0 + p), seed, pp_carve(slots + (size_t)p * slot_stride, N), lane,
                               lam_l, lam_r, loglam_l, loglam_r);
             if (c0 == 0 && r > 0) {
                 // ---- every workgroup of the group has published log w_{r-1}: one hop
@@ -827,3 +853,4 @@ __global__ __launch_bounds__(NT, NT / 256) void pp_sweep(const pp_args a) {
         lse[R] = z;
     }
 }
+

@@ -15,6 +15,10 @@ from phylo_amd.datasets import load_dataset, synthetic_alignment
 
 pytestmark = pytest.mark.gpu
 PI = np.full((1, 4), 0.25)
+# the two forms of the whole sweep: launches per rank event (scan, bookkeeping, materialise, merge) and
+# one launch of resident workgroups for the whole sweep
+FORMS = [_ffi.FLAGS_DEFAULT, _ffi.FLAGS_DEFAULT | _ffi.ONE_LAUNCH]
+FORM_IDS = ["launches", "one-launch"]
 
 
 def ctx_for(g, K, Q, jc=False):
@@ -38,7 +42,7 @@ def check(out, ref, what):
     assert out['logZ'] == ref['logZ'], (what, out['logZ'], ref['logZ'])
 
 
-@pytest.mark.parametrize("flags", [_ffi.FLAGS_DEFAULT, _ffi.FLAGS_DEFAULT | _ffi.ONE_LAUNCH], ids=["launches", "one-launch"])
+@pytest.mark.parametrize("flags", FORMS, ids=FORM_IDS)
 def test_primate_gtr_K2048_ten_seeds(flags):
     """BASELINE config 2 (headline): primate.p, jcmodel=false initial Q, K = 2048, seeds 0..9.  max |delta log Z| = 0 and
     identical ancestor indices at every rank event (SURVEY 8d asks <= 1e-6 |log Z|)."""
@@ -56,7 +60,7 @@ def test_primate_gtr_K2048_ten_seeds(flags):
     ctx.close()
 
 
-@pytest.mark.parametrize("flags", [_ffi.FLAGS_DEFAULT, _ffi.FLAGS_DEFAULT | _ffi.ONE_LAUNCH], ids=["launches", "one-launch"])
+@pytest.mark.parametrize("flags", FORMS, ids=FORM_IDS)
 def test_primate_jc69_K512(flags):
     """BASELINE config 1: primate.p, JC69 closed form, K = 512, seeds 0..9."""
     g = load_dataset('primate_data')['genome']
@@ -83,7 +87,7 @@ def test_primate_gtr_twisting_K2048():
     ctx.close()
 
 
-@pytest.mark.parametrize("flags", [_ffi.FLAGS_DEFAULT, _ffi.FLAGS_DEFAULT | _ffi.ONE_LAUNCH], ids=["launches", "one-launch"])
+@pytest.mark.parametrize("flags", FORMS, ids=FORM_IDS)
 def test_ds1_K4096_one_gpu(flags):
     """BASELINE config 3's workload on one GPU: DS1 (27 taxa, 1949 sites, 10 746 gap cells), K = 4096."""
     g = load_dataset('hohna_data_1')['genome']
@@ -147,8 +151,11 @@ def test_one_launch_sweep_shapes(dataset, K, jc):
     ctx = ctx_for(g, K, Q, jc=jc)
     one = _ffi.FLAGS_DEFAULT | _ffi.ONE_LAUNCH
     for seed in (0, 4):
+        four = ctx.sweep(seed)                                  # launches per rank event
+        assert four['stats']['n_launches'] > 3 * (N - 1)
         out = ctx.sweep(seed, flags=one)
         assert out['stats']['n_launches'] == 1, "the one-launch form did not run"
+        check(four, out, "launches vs one launch, %s K=%d seed %d" % (dataset, K, seed))
         ref = CO.sweep(g, Q, PI, lam, lam, K, seed, jc=jc, want_nodes=(K <= 300))
         check(out, ref, "%s K=%d seed %d" % (dataset, K, seed))
         if K <= 300:                                            # dead and adopted nodes alike, written on demand afterwards
@@ -160,7 +167,7 @@ def test_one_launch_sweep_shapes(dataset, K, jc):
     ctx.close()
 
 
-def test_one_launch_quirk_flag_generic_rows_and_special_values():
+def test_whole_sweep_forms_quirk_flag_generic_rows_and_special_values():
     """Asymmetric Q, non-uniform pi, per-rank rates, log-q form; a leaf row that is neither one-hot nor all-ones (no leaf
     codes); an all-zero leaf row (site likelihood 0 -> log = -inf: the merge's out-of-line branch for factors that are not
     positive normal numbers)."""
@@ -179,10 +186,11 @@ def test_one_launch_quirk_flag_generic_rows_and_special_values():
         ctx = _ffi.Context(K, N, g.shape[1])
         ctx.set_leaves(g)
         ctx.set_model(Q, pi, lam_l, lam_r)
-        for flags in (1, 0):
-            out = ctx.sweep(21, flags=flags | _ffi.ONE_LAUNCH)
-            assert out['stats']['n_launches'] == 1
-            ref = CO.sweep(g, Q, pi, lam_l, lam_r, K, 21, flags=flags)
+        for flags in (1, 0, 1 | _ffi.ONE_LAUNCH, 0 | _ffi.ONE_LAUNCH):
+            out = ctx.sweep(21, flags=flags)
+            if flags & _ffi.ONE_LAUNCH:
+                assert out['stats']['n_launches'] == 1
+            ref = CO.sweep(g, Q, pi, lam_l, lam_r, K, 21, flags=flags & 1)
             np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
             lw, rw = out['log_weights'], ref['log_weights']
             both_nan = np.isnan(lw) & np.isnan(rw)
@@ -193,20 +201,21 @@ def test_one_launch_quirk_flag_generic_rows_and_special_values():
         ctx.close()
 
 
-@pytest.mark.parametrize("G,Kg", [(3, 32), (8, 256), (5, 7)])
-def test_one_launch_batched_sweeps(G, Kg):
-    """G independent sweeps in one launch: every group has its own arrival counter and is bit for bit the Kg-particle sweep
-    of its seed."""
+@pytest.mark.parametrize("G,Kg", [(3, 32), (8, 256), (5, 7), (10, 2048)])
+def test_batched_sweeps_in_every_form(G, Kg):
+    """G independent sweeps per set of launches (one launch: every group has its own arrival counter; launches per rank
+    event: one scan workgroup per group): each group is bit for bit the Kg-particle sweep of its seed."""
     g = load_dataset('primate_data')['genome']
     N = g.shape[0]
     Q = O.get_Q(O.init_y_q())
     lam = np.full(N - 1, 10.0)
     ctx = ctx_for(g, G * Kg, Q)
     seeds = [100 + 7 * i for i in range(G)]
-    for rep in range(2):
-        ctx.sweep_batch_async(seeds, flags=_ffi.FLAGS_DEFAULT | _ffi.ONE_LAUNCH)
+    for rep, fl in enumerate((_ffi.ONE_LAUNCH, 0, _ffi.ONE_LAUNCH)):
+        ctx.sweep_batch_async(seeds, flags=_ffi.FLAGS_DEFAULT | fl)
         out = ctx.sweep_fetch()
-        assert out['stats']['n_launches'] == 1
+        if fl == _ffi.ONE_LAUNCH:
+            assert out['stats']['n_launches'] == 1
         logz = ctx.sweep_fetch_logz(G)
         refs = [CO.sweep(g, Q, PI, lam, lam, Kg, s) for s in seeds]
         for key in ('log_weights', 'log_likelihood'):
