@@ -30,6 +30,39 @@ def main():
     twist_M = int(os.environ.get('PHYLO_TEST_TWIST_M', '0'))
     flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if twist_M else 0)
     batch = int(os.environ.get('PHYLO_TEST_BATCH', '0'))
+    if batch and int(os.environ.get('PHYLO_TEST_INFLIGHT', '1')) > 1:
+        # bench.py's exact loop at N > 1: several contexts on ONE shared communicator, each carrying `batch` independent sweeps,
+        # advanced rank event by rank event: first halves of all contexts (lazy nodes: marks, owners' writes, their barrier),
+        # then the second halves (bookkeeping, merge, all-gather, scan); context i uses seeds seed + 100 i + 10 j
+        inflight = int(os.environ['PHYLO_TEST_INFLIGHT'])
+        group = [ctx]
+        for i in range(1, inflight):
+            c2 = _ffi.Context(K, N, S, device=int(os.environ.get('PHYLO_TEST_DEVICE', '0')))
+            c2.set_leaves(g)
+            c2.set_model(Q, pi, lam, lam, jc69_closed_form=jc)
+            c2.comm_share(ctx)
+            group.append(c2)
+        for rep in range(n_sweeps):
+            for i, c in enumerate(group):
+                c.sweep_batch_begin([seed + 100 * i + 10 * j for j in range(batch)], flags=flags)
+            for _ in range(N - 1):
+                for c in group:
+                    c.sweep_step_a()
+                for c in group:
+                    c.sweep_step()
+            for c in group:
+                c.sweep_finish()
+        outs = {}
+        for i, c in enumerate(group):
+            r = c.sweep_fetch()
+            outs['log_weights%d' % i] = r['log_weights']
+            outs['ancestors%d' % i] = r['ancestors']
+            outs['logz%d' % i] = c.sweep_fetch_logz(batch)
+        np.savez(out, k0=ctx.k0, **outs)
+        for c in reversed(group[1:]):
+            c.close()
+        ctx.close()
+        return
     if batch:                                      # G independent sweeps in one sharded context (bench.py at N > 1)
         seeds = [seed + 10 * i for i in range(batch)]
         for rep in range(n_sweeps):

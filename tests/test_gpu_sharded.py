@@ -178,6 +178,33 @@ def test_batched_sweeps_on_sharded_contexts(world, G, Kg):
         assert list(p['logz']) == [ref['logZ'] for ref in refs]                        # every rank holds every estimate
 
 
+@pytest.mark.parametrize("transport,world", [('hostshm', 2), ('rccl', 1)])
+def test_bench_loop_at_n_gt_1(transport, world):
+    """bench.py's exact N > 1 loop: 2 ranks x 2 contexts on one shared communicator x 3 batched sweeps per context,
+    phylo_sweep_batch_begin + phylo_sweep_step_a + phylo_sweep_step + phylo_sweep_finish, lazy nodes (the default): every one
+    of the 6 sweeps equals the oracle's sweep of its seed.  Also with the real library on a one-rank world running the complete
+    sharded protocol."""
+    G, Kg, seed, inflight = 3, 32, 21, 2
+    env = {'PHYLO_TEST_BATCH': str(G), 'PHYLO_TEST_INFLIGHT': str(inflight)}
+    if transport == 'rccl':
+        env.update(PHYLO_COMM_FORCE_RCCL='1', PHYLO_REHEARSE_SHARDED='1')
+    parts = run_world(world, G * Kg, 'primate_data', seed, False, n_sweeps=2, transport=transport, extra_env=env)
+    g = load_dataset('primate_data')['genome']
+    N = g.shape[0]
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    Kl = G * Kg // world
+    for i in range(inflight):
+        refs = [CO.sweep(g, Q, PI, lam, lam, Kg, seed + 100 * i + 10 * j) for j in range(G)]
+        lw = np.concatenate([r['log_weights'] for r in refs], axis=1)
+        anc = np.concatenate([r['ancestors'] for r in refs], axis=1)
+        for r, p in enumerate(parts):
+            sl = slice(r * Kl, (r + 1) * Kl)
+            assert np.array_equal(p['log_weights%d' % i].view(np.uint64), lw[:, sl].view(np.uint64)), (i, r)
+            np.testing.assert_array_equal(p['ancestors%d' % i], anc[:, sl])
+            assert list(p['logz%d' % i]) == [ref['logZ'] for ref in refs]
+
+
 def test_stepwise_sweep_equals_whole_sweep():
     """phylo_sweep_begin / step / finish, interleaved over two unsharded contexts, against phylo_sweep."""
     g = load_dataset('primate_data_wang')['genome']
