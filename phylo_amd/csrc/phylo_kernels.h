@@ -1419,6 +1419,88 @@ __device__ __forceinline__ double pk_uniform(double v) {
 // log-likelihood is needed, so the row-per-thread form applies -- thread c owns canonical column c (sites c, c+256,
 // ...), reads whole 32-byte rows (or 1-byte codes), and needs no DPP moves: about half the instructions per site of
 // the lane-pair form, whose point is the 16-byte-per-lane store.  Same fma chains, same column products: same bits.
+// ---- row loops of the merge that stores nothing (pk_rank_merge_nostore), written for VALU issue, which binds that kernel with
+//      ~24 waves per CU in flight (profiles/r02_merge_pmc.json): rows and codes are addressed as scalar base + one 32-bit offset
+//      per thread (no 64-bit address arithmetic on the vector pipe, no branch around a load), and two register sets alternate
+//      (sites q and q+1 of the thread), so no register-to-register copies rotate the pipeline.
+typedef __attribute__((ext_vector_type(4))) unsigned int pk_u4;
+typedef __attribute__((address_space(1))) const pk_u4 pk_gu4c;
+typedef __attribute__((address_space(1))) const uint8_t pk_gu8c;
+struct pk_rowregs { pk_u4 l0, l1, r0, r1; unsigned int cl, cr; };
+// wave-uniform base (scalar registers) + one 32-bit byte offset per thread: hipcc then emits the `saddr` form of global_load, with
+// no 64-bit address arithmetic on the vector pipe.  The site index is clamped (a site past the end re-reads the last one and is
+// not used), so no branch surrounds a load.
+__device__ __forceinline__ const char* pk_uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+}
+template <bool CL, bool CR>
+__device__ __forceinline__ void pk_rows_load(pk_rowregs& x, const char* bl, const char* br, int s, int S) {
+    const unsigned int sc = (unsigned int)(s < S ? s : S - 1);
+    if constexpr (CL) x.cl = *(pk_gu8c*)(bl + sc);
+    else { x.l0 = *(pk_gu4c*)(bl + sc * 32u); x.l1 = *(pk_gu4c*)(bl + sc * 32u + 16u); }
+    if constexpr (CR) x.cr = *(pk_gu8c*)(br + sc);
+    else { x.r0 = *(pk_gu4c*)(br + sc * 32u); x.r1 = *(pk_gu4c*)(br + sc * 32u + 16u); }
+}
+__device__ __forceinline__ double pk_u2d(unsigned int lo, unsigned int hi) { return __hiloint2double((int)hi, (int)lo); }
+template <bool CL, bool CR>
+__device__ __forceinline__ void pk_rows_site(const pk_rowregs& x, const double (&Pl)[16], const double (&Pr)[16], const double (*tabL)[4],
+                                             const double (*tabR)[4], const double* lik25, const double (&pi)[4], pm_lp& col) {
+    if constexpr (CL && CR) {
+        pm_lp_mul(col, lik25[x.cl * 5 + x.cr]);
+    } else {
+        double lpv[4], rpv[4], o[4];
+        if constexpr (CL) {
+            const pk_d2 a = *reinterpret_cast<const pk_d2*>(&tabL[x.cl][0]), b = *reinterpret_cast<const pk_d2*>(&tabL[x.cl][2]);
+            lpv[0] = a.x; lpv[1] = a.y; lpv[2] = b.x; lpv[3] = b.y;
+        } else {
+            const double Lv[4] = {pk_u2d(x.l0.x, x.l0.y), pk_u2d(x.l0.z, x.l0.w), pk_u2d(x.l1.x, x.l1.y), pk_u2d(x.l1.z, x.l1.w)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double v = Lv[0] * Pl[j];
+                v = pm_fma(Lv[1], Pl[4 + j], v);
+                v = pm_fma(Lv[2], Pl[8 + j], v);
+                lpv[j] = pm_fma(Lv[3], Pl[12 + j], v);
+            }
+        }
+        if constexpr (CR) {
+            const pk_d2 a = *reinterpret_cast<const pk_d2*>(&tabR[x.cr][0]), b = *reinterpret_cast<const pk_d2*>(&tabR[x.cr][2]);
+            rpv[0] = a.x; rpv[1] = a.y; rpv[2] = b.x; rpv[3] = b.y;
+        } else {
+            const double Rv[4] = {pk_u2d(x.r0.x, x.r0.y), pk_u2d(x.r0.z, x.r0.w), pk_u2d(x.r1.x, x.r1.y), pk_u2d(x.r1.z, x.r1.w)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double v = Rv[0] * Pr[j];
+                v = pm_fma(Rv[1], Pr[4 + j], v);
+                v = pm_fma(Rv[2], Pr[8 + j], v);
+                rpv[j] = pm_fma(Rv[3], Pr[12 + j], v);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = lpv[j] * rpv[j];
+        pm_lp_mul(col, pk_site_lik(pi, o));
+    }
+}
+template <bool CL, bool CR>
+__device__ __forceinline__ void pk_rows_loop(int S, const double* Lp, const double* Rp, const uint8_t* Lc, const uint8_t* Rc,
+                                             const double (&Pl)[16], const double (&Pr)[16], const double (*tabL)[4],
+                                             const double (*tabR)[4], const double* lik25, const double (&pi)[4], pm_lp& col) {
+    const char* bl = pk_uniform_ptr(CL ? (const void*)Lc : (const void*)Lp);
+    const char* br = pk_uniform_ptr(CR ? (const void*)Rc : (const void*)Rp);
+    pk_rowregs A, B;
+    int s = threadIdx.x;
+    pk_rows_load<CL, CR>(A, bl, br, s, S);
+    #pragma unroll 1
+    for (; s < S; s += 2 * PK_COLS) {
+        pk_rows_load<CL, CR>(B, bl, br, s + PK_COLS, S);
+        pk_rows_site<CL, CR>(A, Pl, Pr, tabL, tabR, lik25, pi, col);
+        pk_rows_load<CL, CR>(A, bl, br, s + 2 * PK_COLS, S);
+        if (s + PK_COLS < S) pk_rows_site<CL, CR>(B, Pl, Pr, tabL, tabR, lik25, pi, col);
+    }
+}
+
 __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_rank_args a) {
     __shared__ double cols[PK_COLS];
     __shared__ double sh4[4];
@@ -1447,11 +1529,11 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_ran
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     pm_lp col = pm_lp_init();
     if (codedL) {
-        if (codedR) pk_coded_row(a, Lc, Rc, lik25, col);
-        else pk_twist_row<true, false>(a, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col);
+        if (codedR) pk_rows_loop<true, true>(a.S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, lik25, pi, col);
+        else pk_rows_loop<true, false>(a.S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, lik25, pi, col);
     } else {
-        if (codedR) pk_twist_row<false, true>(a, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col);
-        else pk_twist_row<false, false>(a, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, pi, col);
+        if (codedR) pk_rows_loop<false, true>(a.S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, lik25, pi, col);
+        else pk_rows_loop<false, false>(a.S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, lik25, pi, col);
     }
     cols[tid] = pm_lp_finish(col);
     __syncthreads();
