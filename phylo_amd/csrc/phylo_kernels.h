@@ -1067,6 +1067,7 @@ __device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int 
     // event rho by global particle kappa, which lives in the pool of rank kappa / Kloc (read in place over
     // xGMI when that is not this GPU)
     if (id < a.N) return a.leaves + (size_t)id * node_sz;
+    if (a.Kloc == a.K) return a.pool + (size_t)(id - a.N) * node_sz;      // one rank: no dependent load of the owner's base
     const int x = id - a.N, rho = x / a.K, kap = x - rho * a.K, owner = kap / a.Kloc;
     return a.pool_ptrs[owner] + ((size_t)rho * a.Kloc + (kap - owner * a.Kloc)) * node_sz;
 }
@@ -1485,13 +1486,22 @@ __device__ __forceinline__ void pk_rows_site(const pk_rowregs& x, const double (
 }
 template <bool CL, bool CR>
 __device__ __forceinline__ void pk_rows_loop(int S, const double* Lp, const double* Rp, const uint8_t* Lc, const uint8_t* Rc,
-                                             const double (&Pl)[16], const double (&Pr)[16], const double (*tabL)[4],
-                                             const double (*tabR)[4], const double* lik25, const double (&pi)[4], pm_lp& col) {
+                                             const double* Pu, const double* pi4, const double (&Pl)[16], const double (&Pr)[16],
+                                             double (*tabL)[4], double (*tabR)[4], double* lik25, const double (&pi)[4], pm_lp& col) {
     const char* bl = pk_uniform_ptr(CL ? (const void*)Lc : (const void*)Lp);
     const char* br = pk_uniform_ptr(CR ? (const void*)Rc : (const void*)Rp);
     pk_rowregs A, B;
     int s = threadIdx.x;
-    pk_rows_load<CL, CR>(A, bl, br, s, S);
+    pk_rows_load<CL, CR>(A, bl, br, s, S);                 // the first rows / codes travel while the leaf tables are built
+    if constexpr (CL || CR) {                              // (the whole workgroup takes the same variant: the barriers are uniform)
+        if (threadIdx.x < 32) pk_build_leaf_table(Pu, tabL, threadIdx.x);
+        else if (threadIdx.x < 64) pk_build_leaf_table(Pu + 16, tabR, threadIdx.x - 32);
+        __syncthreads();
+    }
+    if constexpr (CL && CR) {
+        pk_build_lik25(tabL, tabR, pi4, lik25, threadIdx.x);
+        __syncthreads();
+    }
     #pragma unroll 1
     for (; s < S; s += 2 * PK_COLS) {
         pk_rows_load<CL, CR>(B, bl, br, s + PK_COLS, S);
@@ -1517,23 +1527,14 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_ran
     double Pl[16], Pr[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) { Pl[u] = Pu[u]; Pr[u] = Pu[16 + u]; }   // uniform address, nothing stored yet: scalar loads
-    if (codedL || codedR) {
-        if (tid < 32) pk_build_leaf_table(Pu, tabL, tid);
-        else if (tid < 64) pk_build_leaf_table(Pu + 16, tabR, tid - 32);
-        __syncthreads();
-    }
-    if (codedL && codedR) {
-        pk_build_lik25(tabL, tabR, a.pi, lik25, tid);
-        __syncthreads();
-    }
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     pm_lp col = pm_lp_init();
     if (codedL) {
-        if (codedR) pk_rows_loop<true, true>(a.S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, lik25, pi, col);
-        else pk_rows_loop<true, false>(a.S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, lik25, pi, col);
+        if (codedR) pk_rows_loop<true, true>(a.S, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
+        else pk_rows_loop<true, false>(a.S, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
     } else {
-        if (codedR) pk_rows_loop<false, true>(a.S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, lik25, pi, col);
-        else pk_rows_loop<false, false>(a.S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, lik25, pi, col);
+        if (codedR) pk_rows_loop<false, true>(a.S, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
+        else pk_rows_loop<false, false>(a.S, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
     }
     cols[tid] = pm_lp_finish(col);
     __syncthreads();
