@@ -915,7 +915,9 @@ static int sweep_step_a(phylo_ctx* c) {
     b.lazy = 1; b.mark = c->d_mark; b.child_all = c->d_child; b.Pmat_all = c->d_Pmat;
     hipLaunchKernelGGL(pk_all_marks, dim3(cdiv(K, 4)), dim3(64), 0, c->stream, b);
     CHK(launch_check(c, "pk_all_marks"));
-    hipLaunchKernelGGL(pk_materialize_adopted, dim3(S <= 4096 ? 1 : cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
+    // large launches of small nodes (batched sweeps): dispatching one workgroup per particle costs more than the few writes
+            if (S <= 4096 && Kl > 8192) hipLaunchKernelGGL(pk_materialize_adopted_grouped, dim3(cdiv(Kl, PK_MAT_GROUP)), dim3(PK_COLS), 0, c->stream, b);
+            else hipLaunchKernelGGL(pk_materialize_adopted, dim3(S <= 4096 ? 1 : cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
     CHK(launch_check(c, "pk_materialize_adopted"));
     double* rows[1] = {c->d_sync};
     CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
@@ -1044,7 +1046,9 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
         if (lazy && r > 0 && !(c->run.local_book && !twist)) {   // (sharded with owner-held tables: done in sweep_step_a)
             // few nodes are marked, almost every workgroup leaves at once: one workgroup per particle for small nodes (a quarter
             // of the empty workgroups), site tiles for large ones (a marked node is then not limited to one CU's bandwidth)
-            hipLaunchKernelGGL(pk_materialize_adopted, dim3(S <= 4096 ? 1 : cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
+            // large launches of small nodes (batched sweeps): dispatching one workgroup per particle costs more than the few writes
+            if (S <= 4096 && Kl > 8192) hipLaunchKernelGGL(pk_materialize_adopted_grouped, dim3(cdiv(Kl, PK_MAT_GROUP)), dim3(PK_COLS), 0, c->stream, b);
+            else hipLaunchKernelGGL(pk_materialize_adopted, dim3(S <= 4096 ? 1 : cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
             CHK(launch_check(c, "pk_materialize_adopted"));
             ++launches;
             if (c->comm.transport != 0) {      // peers read these nodes in place: order them before every rank's merge

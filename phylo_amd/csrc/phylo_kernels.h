@@ -961,6 +961,28 @@ __global__ __launch_bounds__(PK_COLS) void pk_materialize_adopted(const pk_rank_
     pk_materialize_node(a, a.r - 1, node, threadIdx.x, PK_COLS, s0, s1);
 }
 
+// The same for small nodes, where nearly every workgroup of the grid above would start only to read one mark and leave
+// (dispatching 20 480 such workgroups costs 8 us): a workgroup takes PK_MAT_GROUP particles, one wave reads their marks with one
+// coalesced load, and the marked nodes -- a handful on real data -- are written one after the other by the whole workgroup.
+#define PK_MAT_GROUP 64
+__global__ __launch_bounds__(PK_COLS) void pk_materialize_adopted_grouped(const pk_rank_args a) {
+    __shared__ unsigned long long marked;
+    const int k0 = blockIdx.x * PK_MAT_GROUP;                   // local particle slots k0 .. k0 + PK_MAT_GROUP - 1
+    if (threadIdx.x < 64) {
+        const int k = k0 + (int)threadIdx.x;
+        const unsigned int m = (threadIdx.x < PK_MAT_GROUP && k < a.Kloc) ? a.mark[(size_t)(a.r - 1) * a.K + a.k0 + k] : 0u;
+        const unsigned long long b = __ballot(m != 0u);
+        if (threadIdx.x == 0) marked = b;
+    }
+    __syncthreads();
+    unsigned long long todo = marked;
+    while (todo) {                                              // workgroup-uniform
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        pk_materialize_node(a, a.r - 1, a.k0 + k0 + j, threadIdx.x, PK_COLS, 0, a.S);
+    }
+}
+
 // every node of rank event rho (test surface: phylo_sweep_node after a lazy sweep)
 __global__ __launch_bounds__(PK_COLS) void pk_materialize_rank(const pk_rank_args a, int rho) {
     const int k = blockIdx.x;
