@@ -1506,15 +1506,29 @@ __device__ __forceinline__ void pk_rows_site(const pk_rowregs& x, const double (
         pm_lp_mul(col, pk_site_lik(pi, o));
     }
 }
+// the loop alone: sites tid, tid + 256, ... of one (left, right) pair with the first register set already loaded
+template <bool CL, bool CR>
+__device__ __forceinline__ void pk_rows_run(int S, const char* bl, const char* br, pk_rowregs& A, const double (&Pl)[16], const double (&Pr)[16],
+                                            const double (*tabL)[4], const double (*tabR)[4], const double* lik25, const double (&pi)[4],
+                                            pm_lp& col) {
+    pk_rowregs B;
+    int s = threadIdx.x;
+    #pragma unroll 1
+    for (; s < S; s += 2 * PK_COLS) {
+        pk_rows_load<CL, CR>(B, bl, br, s + PK_COLS, S);
+        pk_rows_site<CL, CR>(A, Pl, Pr, tabL, tabR, lik25, pi, col);
+        pk_rows_load<CL, CR>(A, bl, br, s + 2 * PK_COLS, S);
+        if (s + PK_COLS < S) pk_rows_site<CL, CR>(B, Pl, Pr, tabL, tabR, lik25, pi, col);
+    }
+}
 template <bool CL, bool CR>
 __device__ __forceinline__ void pk_rows_loop(int S, const double* Lp, const double* Rp, const uint8_t* Lc, const uint8_t* Rc,
                                              const double* Pu, const double* pi4, const double (&Pl)[16], const double (&Pr)[16],
                                              double (*tabL)[4], double (*tabR)[4], double* lik25, const double (&pi)[4], pm_lp& col) {
     const char* bl = pk_uniform_ptr(CL ? (const void*)Lc : (const void*)Lp);
     const char* br = pk_uniform_ptr(CR ? (const void*)Rc : (const void*)Rp);
-    pk_rowregs A, B;
-    int s = threadIdx.x;
-    pk_rows_load<CL, CR>(A, bl, br, s, S);                 // the first rows / codes travel while the leaf tables are built
+    pk_rowregs A;
+    pk_rows_load<CL, CR>(A, bl, br, threadIdx.x, S);       // the first rows / codes travel while the leaf tables are built
     if constexpr (CL || CR) {                              // (the whole workgroup takes the same variant: the barriers are uniform)
         if (threadIdx.x < 32) pk_build_leaf_table(Pu, tabL, threadIdx.x);
         else if (threadIdx.x < 64) pk_build_leaf_table(Pu + 16, tabR, threadIdx.x - 32);
@@ -1524,12 +1538,35 @@ __device__ __forceinline__ void pk_rows_loop(int S, const double* Lp, const doub
         pk_build_lik25(tabL, tabR, pi4, lik25, threadIdx.x);
         __syncthreads();
     }
+    pk_rows_run<CL, CR>(S, bl, br, A, Pl, Pr, tabL, tabR, lik25, pi, col);
+}
+// contract v4 row (one coded leaf, one internal root X): lik[s] = X[s] . v_code[s], same two-register-set loop
+__device__ __forceinline__ void pk_rows_v4(int S, const double* Xp, const uint8_t* cd, const double (*vtab)[4], pm_lp& col) {
+    const char* bx = pk_uniform_ptr(Xp);
+    const char* bc = pk_uniform_ptr(cd);
+    pk_u4 a0, a1, b0, b1;
+    unsigned int ca, cb;
+    auto load = [&](pk_u4& x0, pk_u4& x1, unsigned int& c, int s) {
+        const unsigned int sc = (unsigned int)(s < S ? s : S - 1);
+        x0 = *(pk_gu4c*)(bx + sc * 32u); x1 = *(pk_gu4c*)(bx + sc * 32u + 16u);
+        c = *(pk_gu8c*)(bc + sc);
+    };
+    auto site = [&](const pk_u4& x0, const pk_u4& x1, unsigned int c) {
+        const pk_d2 va = *reinterpret_cast<const pk_d2*>(&vtab[c][0]), vb = *reinterpret_cast<const pk_d2*>(&vtab[c][2]);
+        double lik = pk_u2d(x0.x, x0.y) * va.x;
+        lik = pm_fma(pk_u2d(x0.z, x0.w), va.y, lik);
+        lik = pm_fma(pk_u2d(x1.x, x1.y), vb.x, lik);
+        lik = pm_fma(pk_u2d(x1.z, x1.w), vb.y, lik);
+        pm_lp_mul(col, lik);
+    };
+    int s = threadIdx.x;
+    load(a0, a1, ca, s);
     #pragma unroll 1
     for (; s < S; s += 2 * PK_COLS) {
-        pk_rows_load<CL, CR>(B, bl, br, s + PK_COLS, S);
-        pk_rows_site<CL, CR>(A, Pl, Pr, tabL, tabR, lik25, pi, col);
-        pk_rows_load<CL, CR>(A, bl, br, s + 2 * PK_COLS, S);
-        if (s + PK_COLS < S) pk_rows_site<CL, CR>(B, Pl, Pr, tabL, tabR, lik25, pi, col);
+        load(b0, b1, cb, s + PK_COLS);
+        site(a0, a1, ca);
+        load(a0, a1, ca, s + 2 * PK_COLS);
+        if (s + PK_COLS < S) site(b0, b1, cb);
     }
 }
 
@@ -1706,8 +1743,8 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist
             const double* Rp = pk_node_ptr(a, idr);
             if (ta.codes && ((idl < a.N) != (idr < a.N))) {       // coded leaf x internal root: contract v4
                 pm_lp colv = pm_lp_init();
-                if (idl < a.N) pk_twist_row_v4(a, Rp, ta.codes + (size_t)idl * a.S, vsh[q], colv);
-                else pk_twist_row_v4(a, Lp, ta.codes + (size_t)idr * a.S, vsh[q], colv);
+                if (idl < a.N) pk_rows_v4(a.S, Rp, ta.codes + (size_t)idl * a.S, vsh[q], colv);
+                else pk_rows_v4(a.S, Lp, ta.codes + (size_t)idr * a.S, vsh[q], colv);
                 cols[q][tid] = pm_lp_finish(colv);
                 continue;
             }
@@ -1719,9 +1756,22 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist
             const uint8_t* Lc = a.leaf_codes + (cL ? (size_t)idl * a.S : 0);
             const uint8_t* Rc = a.leaf_codes + (cR ? (size_t)idr * a.S : 0);
             if (cL && cR) pk_twist_row<true, true>(a, Lp, Rp, Lc, Rc, Pl, Pr, tab[q][0], tab[q][1], pi, col);
-            else if (cL) pk_twist_row<true, false>(a, Lp, Rp, Lc, Rc, Pl, Pr, tab[q][0], tab[q][1], pi, col);
-            else if (cR) pk_twist_row<false, true>(a, Lp, Rp, Lc, Rc, Pl, Pr, tab[q][0], tab[q][1], pi, col);
-            else pk_twist_row<false, false>(a, Lp, Rp, Lc, Rc, Pl, Pr, tab[q][0], tab[q][1], pi, col);
+            else {
+                pk_rowregs A;
+                if (cL) {
+                    const char* bl = pk_uniform_ptr(Lc); const char* br = pk_uniform_ptr(Rp);
+                    pk_rows_load<true, false>(A, bl, br, tid, a.S);
+                    pk_rows_run<true, false>(a.S, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
+                } else if (cR) {
+                    const char* bl = pk_uniform_ptr(Lp); const char* br = pk_uniform_ptr(Rc);
+                    pk_rows_load<false, true>(A, bl, br, tid, a.S);
+                    pk_rows_run<false, true>(a.S, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
+                } else {
+                    const char* bl = pk_uniform_ptr(Lp); const char* br = pk_uniform_ptr(Rp);
+                    pk_rows_load<false, false>(A, bl, br, tid, a.S);
+                    pk_rows_run<false, false>(a.S, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
+                }
+            }
             cols[q][tid] = pm_lp_finish(col);
         }
         __syncthreads();
