@@ -89,3 +89,28 @@ def test_chain_rules_to_reference_variables():
         assert abs(fd - v['d_loglam_l'][i]) < 2e-6 * max(1.0, abs(fd))
         fd = (val(y_q, y_s, a_l, a_r + d) - val(y_q, y_s, a_l, a_r - d)) / (2 * h)
         assert abs(fd - v['d_loglam_r'][i]) < 2e-6 * max(1.0, abs(fd))
+
+
+def test_twisted_forward_matches_sweep_oracle():
+    genome, Q, pi, ll, lr, K = _case(N=5, S=12, K=8)
+    f = G.forward_twisted(genome, Q, pi, ll, lr, K, 2, seed=31)
+    s = O.sweep_twisted(genome, Q, pi, ll, lr, K, 2, 31)
+    np.testing.assert_allclose(f['lw'], s['log_weights'], rtol=0, atol=1e-9)
+    assert abs(f['logZ'] - s['logZ']) < 1e-9
+    assert np.array_equal(np.stack(f['co']), s['merges'])
+    f2 = G.forward_twisted(genome, Q, pi, ll, lr, K, 2, seed=31, struct=f['struct'])
+    assert f2['logZ'] == f['logZ']
+
+
+@pytest.mark.parametrize("M", [1, 3])
+def test_twisted_gradient_matches_central_differences(M):
+    """vncsmc.py:295-416: the potentials of every (pair, sub-sample) are differentiated, the draws are not."""
+    genome, Q, pi, ll, lr, K = _case(N=5, S=12, K=8)
+    g = G.sweep_grad_twisted(genome, Q, pi, ll, lr, K, M, seed=31)
+    st = g['struct']
+    for which, key, idxs in (('lam_l', 'd_lam_l', [(0,), (2,), (3,)]), ('lam_r', 'd_lam_r', [(1,), (3,)]),
+                             ('pi', 'd_pi', [(0,), (3,)]), ('Q', 'd_Q', [(0, 0), (1, 2), (3, 1)])):
+        for idx in idxs:
+            fd = G.finite_difference_twisted(genome, Q, pi, ll, lr, K, M, 31, st, which, idx)
+            an = g[key][idx]
+            assert abs(fd - an) <= 2e-6 * max(1.0, abs(an)), (which, idx, fd, an)
