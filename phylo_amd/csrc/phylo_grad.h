@@ -21,8 +21,33 @@
 #define PG_HCHUNK 32                   // parents per chunk of a heavy node
 #define PG_NT 256                      // sites per workgroup of pg_nodes (4 steps of 64 sites)
 
+#define PG_XCH 16                       // (adopter, slot) entries per chunk of pg_twist_xchunks
+
+// The twisted proposal's part of the graph (PHYLO_TWISTING | PHYLO_KEEP_GRAPH).  Rows: one per (rank event, particle,
+// sub-sample j = t M + m of pair t), event r's rows at joff[r] + k J_r + j with J_r = C(N-r, 2) M.
+struct pg_twist {
+    int M;
+    const int64_t* joff;               // [R+1]
+    const int32_t* roots_ad;           // [R][K][N] adopted (resampled) root tables
+    const double* tw_b;                // [rows][2] branch lengths of every sub-sample
+    const double* tw_P;                // [rows][32] their transition matrices
+    const double* pot;                 // [rows] look-ahead potentials
+    const double* chosen;              // [R][K] chosen sub-sample
+    double* tau;                       // [rows] d logZ / d pot
+    double* ctw;                       // [R][K][N] coefficient of sum_s log(pi . X) of every slot of the adopted table
+    double* twpart;                    // [rows][PG_PART] Pl_bar, Pr_bar, pi_bar of the row's merge, before the factor tau
+    double* twnode;                    // [R][K][PG_NODEG] per particle: d_lam_l, d_lam_r terms, Q_bar, pi_bar of its rows
+    // adjoints of the adopted roots: entries (adopter * N + slot) grouped by node, cut into chunks of PG_XCH
+    const int32_t* xent;
+    const int32_t *xchunk_node, *xchunk_beg, *xchunk_cnt;
+    const int32_t *xnode_id, *xnode_chunk0, *xnode_nchunks;
+    double* tpart;                     // [chunks of one rank event][S][4]
+};
+
 struct pg_args {
     int N, S, K, R, T, jc;             // T tiles of PG_NT sites per node
+    int twist;                         // the sweep used the twisted proposal: tw is set
+    pg_twist tw;
     const double* leaves;              // [N][S][4]
     const double* pool;                // [R][K][S][4]
     double* adj;                       // [R][K][S][4]: d logZ / d node
@@ -173,6 +198,7 @@ __global__ __launch_bounds__(256) void pg_coeff(pg_args a, int r) {
             const size_t row = (base + idx[j]) * a.N;
             const int p = a.pos[row + slot];
             if (p >= 0) v = v + a.C[row + p];
+            if (a.twist) v = v + a.tw.ctw[row + slot];      // the adopter's potentials subtract post() of every adopted root
         }
         v = pg_wave_sum(v);
     }
@@ -211,6 +237,11 @@ __global__ __launch_bounds__(256) void pg_leafterm(pg_args a) {
             for (int q = 0; q < 4; ++q) acc[q] = acc[q] + c * a.leafpi[x * 4 + q];
         }
     }
+    if (a.twist)                                            // rank event 0 adopts the leaves themselves
+        for (int x = 0; x < a.N; ++x) {
+            const double c = a.tw.ctw[(size_t)k * a.N + x];
+            for (int q = 0; q < 4; ++q) acc[q] = acc[q] + c * a.leafpi[x * 4 + q];
+        }
     for (int q = 0; q < 4; ++q) a.leafterm[k * 4 + q] = acc[q];
 }
 
@@ -336,6 +367,7 @@ __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
         const double lik = ((p0 * x0 + p1 * x1) + p2 * x2) + p3 * x3;
         const double inv = alpha / lik;
         double xb = pj * inv;
+        if (a.twist) xb = xb + orow[soff];                  // what the look-ahead merges of later rank events left (pg_twist_xsum)
         acc[8] = acc[8] + x * inv;
         if (hv >= 0) {
             const double* cp = a.cpart + (size_t)hv * row + soff;
@@ -437,7 +469,9 @@ __global__ __launch_bounds__(256) void pg_scalars(pg_args a) {
         for (int j = 0; j <= r; ++j) prefix = prefix + b[(size_t)j * a.K + k];
         const double lr = lam[r], br_ = b[t];
         const double bbar = (a.nodeg[(size_t)t * PG_NODEG + side] - suffix) + om * lr;
-        a.terms[(size_t)t * 2 + side] = (g * ((double)(r + 1) / lr - prefix) - om * (1.0 / lr - br_)) + bbar * (-br_ / lr);
+        double term = (g * ((double)(r + 1) / lr - prefix) - om * (1.0 / lr - br_)) + bbar * (-br_ / lr);
+        if (a.twist) term = term + a.tw.twnode[(size_t)t * PG_NODEG + side];
+        a.terms[(size_t)t * 2 + side] = term;
     }
 }
 
@@ -454,9 +488,256 @@ __global__ __launch_bounds__(256) void pg_reduce(pg_args a) {
         const int col = q < 4 ? 18 + q : 2 + (q - 4);
         const size_t n = (size_t)a.R * a.K;
         for (size_t i = tid; i < n; i += 256) acc = acc + a.nodeg[i * PG_NODEG + col];
+        if (a.twist)
+            for (size_t i = tid; i < n; i += 256) acc = acc + a.tw.twnode[i * PG_NODEG + col];
         if (q < 4)
             for (int k = tid; k < a.K; k += 256) acc = acc + a.leafterm[k * 4 + q];
     }
     const double t = pg_block_sum(acc, sh);
     if (tid == 0) a.out[o] = t;
+}
+
+
+// ================================================================================================================
+// The twisted proposal (vncsmc.py:295-416): the potentials of EVERY (pair, sub-sample) are differentiated.
+//   pg_twist_tau      tau = omega (softmax_j(pot) - [j chosen]) and the root-slot coefficients ctw
+//   pg_twist_pbar     per row: Pl_bar, Pr_bar, pi_bar of the look-ahead merge (one wave per row)
+//   pg_twist_finish   per particle: branch adjoints -> rate terms, Frechet terms -> Q_bar, of all its rows
+//   pg_twist_xchunks  adjoint rows of the adopted roots (internal nodes only), gathered per node in fixed order
+//   pg_twist_xsum     chunk sums -> adj[node], which pg_nodes then starts from
+// Oracle: oracle/cpu_grad.py sweep_grad_twisted.
+// ================================================================================================================
+__device__ __forceinline__ int pg_pair_index(int r1, int r2, int n) { return r1 * (2 * n - r1 - 1) / 2 + (r2 - r1 - 1); }
+
+// one wave per (rank event, particle); dynamic LDS: J_0 doubles
+__global__ __launch_bounds__(64) void pg_twist_tau(pg_args a) {
+    extern __shared__ __attribute__((aligned(16))) char pg_smem[];
+    double* w = reinterpret_cast<double*>(pg_smem);
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int r = t / a.K, k = t - r * a.K;
+    const int n = a.N - r, M = a.tw.M, J = (n * (n - 1) / 2) * M;
+    const size_t row0 = (size_t)a.tw.joff[r] + (size_t)k * J;
+    const double* pot = a.tw.pot + row0;
+    double mx = -pm_inf();
+    for (int j = lane; j < J; j += 64) {
+        const double v = pot[j];
+        if (!pm_isnan(v) && v > mx) mx = v;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+    }
+    const bool all_bad = !(mx > -pm_inf()) || mx == pm_inf();   // the weights pk_twist_choose drew from
+    double ssum = 0.0;
+    for (int j = lane; j < J; j += 64) {
+        const double v = pot[j];
+        const double wj = all_bad ? 1.0 : (pm_isnan(v) ? 0.0 : pm_exp(v - mx));
+        w[j] = wj;
+        ssum = ssum + wj;
+    }
+    ssum = pg_wave_sum(ssum);
+    const double om = a.om[t];
+    const int jsel = (int)a.tw.chosen[t];
+    const double inv = 1.0 / ssum;
+    for (int j = lane; j < J; j += 64) {
+        const double tj = om * (w[j] * inv - (j == jsel ? 1.0 : 0.0));
+        w[j] = tj;
+        a.tw.tau[row0 + j] = tj;
+    }
+    __syncthreads();
+    for (int x = lane; x < n; x += 64) {
+        double acc = 0.0;
+        for (int y = 0; y < n; ++y) {
+            if (y == x) continue;
+            const int tp = x < y ? pg_pair_index(x, y, n) : pg_pair_index(y, x, n);
+            for (int m = 0; m < M; ++m) acc = acc + w[tp * M + m];
+        }
+        a.tw.ctw[(size_t)t * a.N + x] = -acc;
+    }
+}
+
+struct pg_rowid { int r, k, j, n, J; };
+__device__ __forceinline__ pg_rowid pg_twist_row_of(const pg_args& a, int64_t row) {
+    pg_rowid o;
+    o.r = 0;
+    while (row >= a.tw.joff[o.r + 1]) ++o.r;
+    o.n = a.N - o.r;
+    o.J = (o.n * (o.n - 1) / 2) * a.tw.M;
+    const int64_t rel = row - a.tw.joff[o.r];
+    o.k = (int)(rel / o.J);
+    o.j = (int)(rel - (int64_t)o.k * o.J);
+    return o;
+}
+__device__ __forceinline__ void pg_pair_of(int t, int n, int& il, int& ir) {
+    il = 0;
+    int rem = t;
+    while (rem >= n - 1 - il) { rem -= n - 1 - il; ++il; }
+    ir = il + 1 + rem;
+}
+
+// one wave per row: sums over sites of  X1^T (g o v),  X2^T (g o u),  y / lik   with u = X1 Pl, v = X2 Pr, y = u o v,
+// lik = pi . y, g = pi / lik  (the factor tau is applied by pg_twist_finish)
+__global__ __launch_bounds__(256) void pg_twist_pbar(pg_args a) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t row = (int64_t)blockIdx.x * 4 + wv;
+    if (row >= a.tw.joff[a.R]) return;
+    const pg_rowid id = pg_twist_row_of(a, row);
+    int il, ir;
+    pg_pair_of(id.j / a.tw.M, id.n, il, ir);
+    const int32_t* ro = a.tw.roots_ad + ((size_t)id.r * a.K + id.k) * a.N;
+    const double* X1 = pg_row(a, ro[il]);
+    const double* X2 = pg_row(a, ro[ir]);
+    const double* P = a.tw.tw_P + (size_t)row * 32;
+    double Pl[16], Pr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { Pl[i] = P[i]; Pr[i] = P[16 + i]; }
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    double acc[PG_PART];
+#pragma unroll
+    for (int i = 0; i < PG_PART; ++i) acc[i] = 0.0;
+    for (int s = lane; s < a.S; s += 64) {
+        double x1[4], x2[4], u[4], v[4], y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x1[i] = X1[(size_t)s * 4 + i]; x2[i] = X2[(size_t)s * 4 + i]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u[j] = ((x1[0] * Pl[j] + x1[1] * Pl[4 + j]) + x1[2] * Pl[8 + j]) + x1[3] * Pl[12 + j];
+            v[j] = ((x2[0] * Pr[j] + x2[1] * Pr[4 + j]) + x2[2] * Pr[8 + j]) + x2[3] * Pr[12 + j];
+            y[j] = u[j] * v[j];
+        }
+        const double lik = ((pi[0] * y[0] + pi[1] * y[1]) + pi[2] * y[2]) + pi[3] * y[3];
+        const double inv = 1.0 / lik;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double g = pi[j] * inv;
+            const double gv = g * v[j], gu = g * u[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i * 4 + j] = acc[i * 4 + j] + x1[i] * gv;
+                acc[16 + i * 4 + j] = acc[16 + i * 4 + j] + x2[i] * gu;
+            }
+            acc[32 + j] = acc[32 + j] + y[j] * inv;
+        }
+    }
+    double* out = a.tw.twpart + (size_t)row * PG_PART;
+#pragma unroll
+    for (int i = 0; i < PG_PART; ++i) {
+        const double v = pg_wave_sum(acc[i]);
+        if (lane == 0) out[i] = v;
+    }
+}
+
+// one wave per (rank event, particle): its J rows -> branch adjoints -> rate terms and the Q adjoint
+__global__ __launch_bounds__(64) void pg_twist_finish(pg_args a) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int r = t / a.K, k = t - r * a.K;
+    const int n = a.N - r, J = (n * (n - 1) / 2) * a.tw.M;
+    const size_t row0 = (size_t)a.tw.joff[r] + (size_t)k * J;
+    double Q[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Q[i] = a.Q[i];
+    const double ll = a.lam_l[r], lr = a.lam_r[r];
+    double res[PG_NODEG];
+#pragma unroll
+    for (int i = 0; i < PG_NODEG; ++i) res[i] = 0.0;
+    for (int j = lane; j < J; j += 64) {
+        const size_t row = row0 + j;
+        const double tau = a.tw.tau[row];
+        if (tau == 0.0) continue;
+        const double* pp = a.tw.twpart + row * PG_PART;
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {
+            double Pm[16], QP[16], pb[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { Pm[i] = a.tw.tw_P[row * 32 + side * 16 + i]; pb[i] = tau * pp[side * 16 + i]; }
+            pm_mm4(Q, Pm, QP);
+            double bb = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bb = bb + pb[i] * QP[i];
+            const double b = a.tw.tw_b[row * 2 + side];
+            res[side] = res[side] + bb * (-b / (side ? lr : ll));
+            if (!a.jc) {
+                double At[16], Lf[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) At[i * 4 + jj] = Q[jj * 4 + i] * b;
+                pg_expm4_frechet(At, pb, Lf);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) res[2 + i] = res[2 + i] + b * Lf[i];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) res[18 + q] = res[18 + q] + tau * pp[32 + q];
+    }
+    double* out = a.tw.twnode + (size_t)t * PG_NODEG;
+#pragma unroll
+    for (int i = 0; i < PG_NODEG; ++i) {
+        const double v = pg_wave_sum(res[i]);
+        if (lane == 0) out[i] = v;
+    }
+}
+
+// grid (chunks of rank event r, groups of 256 sites): a thread owns one site of the chunk's node x and walks the chunk's
+// (adopter, slot) entries; for each, every partner slot and sub-sample:  xb += (tau g o v) Pme^T
+__global__ __launch_bounds__(256) void pg_twist_xchunks(pg_args a, int r, int chunk0) {
+    const int ci = blockIdx.x, c = chunk0 + ci;
+    const int x = a.tw.xchunk_node[c], beg = a.tw.xchunk_beg[c], cnt = a.tw.xchunk_cnt[c];
+    const int s = blockIdx.y * 256 + threadIdx.x;
+    const bool live = s < a.S;
+    const size_t soff = (size_t)(live ? s : a.S - 1) * 4;
+    const int n = a.N - r, M = a.tw.M, J = (n * (n - 1) / 2) * M;
+    const double* xr = a.pool + (size_t)(x - a.N) * a.S * 4 + soff;
+    const double x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3];
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    double xb[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int e = 0; e < cnt; ++e) {
+        const int enc = a.tw.xent[beg + e];
+        const int kp = enc / a.N, i = enc - kp * a.N;
+        const int32_t* ro = a.tw.roots_ad + ((size_t)r * a.K + kp) * a.N;
+        const size_t row0 = (size_t)a.tw.joff[r] + (size_t)kp * J;
+        for (int i2 = 0; i2 < n; ++i2) {
+            if (i2 == i) continue;
+            const int side = i > i2 ? 1 : 0;                  // x is the right child of the look-ahead merge
+            const int tp = side ? pg_pair_index(i2, i, n) : pg_pair_index(i, i2, n);
+            const double* sr = pg_row(a, ro[i2]) + soff;
+            const double s0 = sr[0], s1 = sr[1], s2 = sr[2], s3 = sr[3];
+            for (int m = 0; m < M; ++m) {
+                const size_t row = row0 + (size_t)tp * M + m;
+                const double tau = a.tw.tau[row];
+                const double* Pme = a.tw.tw_P + row * 32 + side * 16;
+                const double* Psb = a.tw.tw_P + row * 32 + (1 - side) * 16;
+                double u[4], v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u[j] = ((x0 * Pme[j] + x1 * Pme[4 + j]) + x2 * Pme[8 + j]) + x3 * Pme[12 + j];
+                    v[j] = ((s0 * Psb[j] + s1 * Psb[4 + j]) + s2 * Psb[8 + j]) + s3 * Psb[12 + j];
+                }
+                const double lik = ((pi[0] * (u[0] * v[0]) + pi[1] * (u[1] * v[1])) + pi[2] * (u[2] * v[2])) + pi[3] * (u[3] * v[3]);
+                const double f = tau / lik;
+                const double t0 = (f * pi[0]) * v[0], t1 = (f * pi[1]) * v[1], t2 = (f * pi[2]) * v[2], t3 = (f * pi[3]) * v[3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    xb[q] = xb[q] + (((t0 * Pme[q * 4] + t1 * Pme[q * 4 + 1]) + t2 * Pme[q * 4 + 2]) + t3 * Pme[q * 4 + 3]);
+            }
+        }
+    }
+    if (live) {
+        double* out = a.tw.tpart + ((size_t)ci * a.S + s) * 4;
+        out[0] = xb[0]; out[1] = xb[1]; out[2] = xb[2]; out[3] = xb[3];
+    }
+}
+
+// grid (nodes of rank event r that have entries, groups of 256 elements of a node row)
+__global__ __launch_bounds__(256) void pg_twist_xsum(pg_args a, int node0, int chunk0) {
+    const int ni = node0 + blockIdx.x;
+    const int x = a.tw.xnode_id[ni], c0 = a.tw.xnode_chunk0[ni] - chunk0, nc = a.tw.xnode_nchunks[ni];
+    const size_t e = (size_t)blockIdx.y * 256 + threadIdx.x, row = (size_t)a.S * 4;
+    if (e >= row) return;
+    double* dst = a.adj + (size_t)(x - a.N) * row + e;
+    double v = *dst;
+    for (int c = 0; c < nc; ++c) v = v + a.tw.tpart[(size_t)(c0 + c) * row + e];
+    *dst = v;
 }

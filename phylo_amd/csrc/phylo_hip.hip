@@ -121,6 +121,15 @@ struct phylo_ctx {
     int32_t *d_roots_ad = nullptr, *d_cnt_ad = nullptr;
     double *d_rootll_ad = nullptr, *d_chosen = nullptr, *d_tw_b = nullptr, *d_tw_P = nullptr, *d_pot = nullptr;
     size_t tw_capacity = 0;              // in (particle, sub-sample) entries
+    // ... and its history when the graph is kept (PHYLO_TWISTING | PHYLO_KEEP_GRAPH): every rank event's rows
+    double *d_htw_b = nullptr, *d_htw_P = nullptr, *d_hpot = nullptr, *d_hchosen = nullptr;   // [rows][2], [rows][32], [rows], [R][K]
+    int32_t* d_hroots_ad = nullptr;      // [R][K][N]
+    double *d_tau = nullptr, *d_ctw = nullptr, *d_twpart = nullptr, *d_twnode = nullptr;       // reverse pass
+    int64_t* d_joff = nullptr;           // [R+1]
+    size_t htw_rows = 0;                 // rows the history holds
+    std::vector<int64_t> h_joff;
+    bool last_graph_twist = false;
+    int last_M = 1;
     // graph kept for the reverse pass (PHYLO_KEEP_GRAPH; allocated on first use)
     int32_t *d_hroots = nullptr, *d_hcnt = nullptr, *d_pos = nullptr;   // [(R+1)][K][N], [(R+1)][K][N], [R][K][N]
     double* d_hrootll = nullptr;         // [(R+1)][K][N]
@@ -133,12 +142,13 @@ struct phylo_ctx {
     bool last_final_missing = false;
     std::vector<uint64_t> h_group_seeds;
     std::vector<int32_t> h_csr;          // packed integer lists of the reverse pass (kept alive for the async copy)
+    std::vector<int32_t> h_xlists;       // ... of its twisted part
     hipEvent_t evb0 = nullptr, evb1 = nullptr;
     phylo_stats stats{};
     sweep_run run;
     int n_merge_events = 0;
     // grow-only scratch for the op-level entry points
-    DevBuf scratch[6];
+    DevBuf scratch[8];
     phylo_comm comm;
 };
 
@@ -218,6 +228,14 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_roots_ad = c->d_cnt_ad = nullptr;
     c->d_rootll_ad = c->d_chosen = c->d_tw_b = c->d_tw_P = c->d_pot = nullptr;
     c->tw_capacity = 0;
+    void* ht[] = {c->d_htw_b, c->d_htw_P, c->d_hpot, c->d_hchosen, c->d_hroots_ad, c->d_tau, c->d_ctw, c->d_twpart, c->d_twnode, c->d_joff};
+    for (void* p : ht)
+        if (p) (void)hipFree(p);
+    c->d_htw_b = c->d_htw_P = c->d_hpot = c->d_hchosen = c->d_tau = c->d_ctw = c->d_twpart = c->d_twnode = nullptr;
+    c->d_hroots_ad = nullptr;
+    c->d_joff = nullptr;
+    c->htw_rows = 0;
+    c->last_graph_twist = false;
     void* gr[] = {c->d_hroots, c->d_hcnt, c->d_pos, c->d_hrootll, c->d_adj, c->d_om, c->d_G, c->d_C, c->d_part, c->d_nodeg,
                   c->d_leafpi, c->d_leafterm, c->d_terms, c->d_gout, c->d_ad_off};
     for (void* p : gr)
@@ -733,9 +751,34 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     // Pays when a node is large (HBM-bound merges); on small nodes the extra launch costs more than the stores.
     const bool graph = (flags & PHYLO_KEEP_GRAPH) != 0;
     if (graph) {
-        if (twist) return fail(c, PHYLO_EINVAL, "PHYLO_KEEP_GRAPH needs the plain proposal (no PHYLO_TWISTING)");
         if (c->world != 1) return fail(c, PHYLO_EINVAL, "PHYLO_KEEP_GRAPH needs an unsharded context");
         CHK(ensure_graph_state(c));
+        if (twist) {                                       // every rank event keeps its sub-samples: rows [r][k][J_r]
+            c->h_joff.assign((size_t)R + 1, 0);
+            for (int r = 0; r < R; ++r) c->h_joff[r + 1] = c->h_joff[r] + (int64_t)K * (((N - r) * (N - r - 1)) / 2) * M;
+            const size_t rows = (size_t)c->h_joff[R];
+            if (c->htw_rows < rows) {
+                void* old[] = {c->d_htw_b, c->d_htw_P, c->d_hpot, c->d_tau, c->d_twpart};
+                for (void* p : old)
+                    if (p) (void)hipFree(p);
+                c->d_htw_b = c->d_htw_P = c->d_hpot = c->d_tau = c->d_twpart = nullptr;
+                c->htw_rows = 0;
+                CHK(dalloc(c, &c->d_htw_b, rows * 2));
+                CHK(dalloc(c, &c->d_htw_P, rows * 32));
+                CHK(dalloc(c, &c->d_hpot, rows));
+                CHK(dalloc(c, &c->d_tau, rows));
+                CHK(dalloc(c, &c->d_twpart, rows * PG_PART));
+                c->htw_rows = rows;
+            }
+            if (!c->d_hroots_ad) {
+                CHK(dalloc(c, &c->d_hroots_ad, (size_t)R * K * N));
+                CHK(dalloc(c, &c->d_hchosen, (size_t)R * K));
+                CHK(dalloc(c, &c->d_ctw, (size_t)R * K * N));
+                CHK(dalloc(c, &c->d_twnode, (size_t)R * K * PG_NODEG));
+                CHK(dalloc(c, &c->d_joff, (size_t)R + 1));
+            }
+            HIPCHK(c, hipMemcpyAsync(c->d_joff, c->h_joff.data(), ((size_t)R + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        }
     }
     const bool lazy_ok = !twist && !graph && !(flags & PHYLO_EAGER_NODES) && !c->env.eager_nodes;
     // marks are plain stores and the extra launch costs less than the dead stores it removes at every size measured.
@@ -986,6 +1029,11 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             ta.J = ((N - r) * (N - r - 1) / 2) * M;
             ta.roots_ad = c->d_roots_ad; ta.cnt_ad = c->d_cnt_ad; ta.rootll_ad = c->d_rootll_ad;
             ta.tw_b = c->d_tw_b; ta.tw_P = c->d_tw_P; ta.pot = c->d_pot; ta.chosen = c->d_chosen;
+            if (graph) {                                   // the reverse pass reads every rank event's sub-samples
+                const size_t j0 = (size_t)c->h_joff[r];
+                ta.tw_b = c->d_htw_b + j0 * 2; ta.tw_P = c->d_htw_P + j0 * 32; ta.pot = c->d_hpot + j0;
+                ta.roots_ad = c->d_hroots_ad + plane * r; ta.chosen = c->d_hchosen + (size_t)r * K;
+            }
             ta.Pmat_r = c->d_Pmat + (size_t)r * Kl * 32;
             ta.pair_hist = c->codes_valid ? c->d_pair_hist : nullptr;
             ta.codes = c->codes_valid ? c->d_leaf_codes : nullptr;
@@ -1165,6 +1213,8 @@ int phylo_sweep_finish(phylo_ctx* c) {
     c->run.active = false;
     c->last_lazy = lazy;
     c->last_graph = graph;
+    c->last_graph_twist = graph && twist;
+    c->last_M = c->run.M;
     c->last_G = c->run.G;
     c->last_final_missing = c->run.final_missing;
     c->n_merge_events = timek ? R : 0;
@@ -1377,8 +1427,84 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         if (!chunk_cnt.empty()) memcpy(w, chunk_cnt.data(), chunk_cnt.size() * 4);
         HIPCHK(c, hipMemcpyAsync(c->d_ad_off, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, c->stream));
     }
+    // twisted proposal: the look-ahead merges of rank event r touch every internal node among the adopted roots.  Entries
+    // (adopter, slot) grouped by node (ascending adopter), cut into chunks of PG_XCH; lists for all rank events in one upload.
+    const bool twist = c->last_graph_twist;
+    std::vector<int32_t> ev_chunk0((size_t)R + 1, 0), ev_node0((size_t)R + 1, 0);
+    size_t tw_max_chunks = 0;
+    void *d_xlists = nullptr, *d_tpart = nullptr;
+    size_t n_xent = 0, n_xchunks = 0, n_xnodes = 0;
+    if (twist) {
+        std::vector<int32_t> rad((size_t)R * K * N);
+        HIPCHK(c, hipMemcpy(rad.data(), c->d_hroots_ad, rad.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<int32_t> xent, xc_node, xc_beg, xc_cnt, xn_id, xn_c0, xn_nc;
+        std::vector<int32_t> cnt, first;
+        for (int r = 0; r < R; ++r) {
+            ev_chunk0[r] = (int32_t)xc_node.size();
+            ev_node0[r] = (int32_t)xn_id.size();
+            if (r == 0) continue;                                   // rank event 0 adopts leaves only
+            const int n = N - r;
+            const size_t nn_r = (size_t)r * K;                      // nodes that exist before rank event r
+            cnt.assign(nn_r + 1, 0);
+            const int32_t* tab = rad.data() + (size_t)r * K * N;
+            for (int k = 0; k < K; ++k)
+                for (int i = 0; i < n; ++i) {
+                    const int x = tab[(size_t)k * N + i];
+                    if (x >= N) ++cnt[(size_t)(x - N) + 1];
+                }
+            for (size_t i = 0; i < nn_r; ++i) cnt[i + 1] += cnt[i];
+            const size_t base = xent.size();
+            xent.resize(base + (size_t)cnt[nn_r]);
+            first.assign(cnt.begin(), cnt.end() - 1);
+            for (int k = 0; k < K; ++k)
+                for (int i = 0; i < n; ++i) {
+                    const int x = tab[(size_t)k * N + i];
+                    if (x >= N) xent[base + (size_t)first[x - N]++] = k * N + i;
+                }
+            for (size_t x = 0; x < nn_r; ++x) {
+                const int m = cnt[x + 1] - cnt[x];
+                if (m == 0) continue;
+                xn_id.push_back((int32_t)(x + N));
+                xn_c0.push_back((int32_t)xc_node.size());
+                xn_nc.push_back((m + PG_XCH - 1) / PG_XCH);
+                for (int b = 0; b < m; b += PG_XCH) {
+                    xc_node.push_back((int32_t)(x + N));
+                    xc_beg.push_back((int32_t)(base + cnt[x] + b));
+                    xc_cnt.push_back(m - b < PG_XCH ? m - b : PG_XCH);
+                }
+            }
+            const size_t nch = xc_node.size() - (size_t)ev_chunk0[r];
+            if (nch > tw_max_chunks) tw_max_chunks = nch;
+        }
+        ev_chunk0[R] = (int32_t)xc_node.size();
+        ev_node0[R] = (int32_t)xn_id.size();
+        n_xent = xent.size(); n_xchunks = xc_node.size(); n_xnodes = xn_id.size();
+        std::vector<int32_t>& pk = c->h_xlists;
+        pk.resize(n_xent + 3 * n_xchunks + 3 * n_xnodes + 1);
+        int32_t* w = pk.data();
+        auto put = [&](const std::vector<int32_t>& v) { if (!v.empty()) memcpy(w, v.data(), v.size() * 4); w += v.size(); };
+        put(xent); put(xc_node); put(xc_beg); put(xc_cnt); put(xn_id); put(xn_c0); put(xn_nc);
+        CHK(scratch_get(c, 6, pk.size() * 4, &d_xlists));
+        HIPCHK(c, hipMemcpyAsync(d_xlists, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, c->stream));
+        CHK(scratch_get(c, 7, tw_max_chunks * (size_t)S * 4 * 8, &d_tpart));
+    }
     pg_args g{};
     g.N = N; g.S = S; g.K = K; g.R = R; g.T = T; g.jc = c->jc;
+    g.twist = twist ? 1 : 0;
+    if (twist) {
+        g.tw.M = c->last_M; g.tw.joff = c->d_joff; g.tw.roots_ad = c->d_hroots_ad;
+        g.tw.tw_b = c->d_htw_b; g.tw.tw_P = c->d_htw_P; g.tw.pot = c->d_hpot; g.tw.chosen = c->d_hchosen;
+        g.tw.tau = c->d_tau; g.tw.ctw = c->d_ctw; g.tw.twpart = c->d_twpart; g.tw.twnode = c->d_twnode;
+        const int32_t* xl = (const int32_t*)d_xlists;
+        g.tw.xent = xl; xl += n_xent;
+        g.tw.xchunk_node = xl; xl += n_xchunks;
+        g.tw.xchunk_beg = xl; xl += n_xchunks;
+        g.tw.xchunk_cnt = xl; xl += n_xchunks;
+        g.tw.xnode_id = xl; xl += n_xnodes;
+        g.tw.xnode_chunk0 = xl; xl += n_xnodes;
+        g.tw.xnode_nchunks = xl;
+        g.tw.tpart = (double*)d_tpart;
+    }
     g.heavy_first = c->d_heavy; g.chunk_beg = c->d_chunk_beg; g.chunk_cnt = c->d_chunk_cnt; g.cpart = (double*)cpart;
     g.leaves = c->d_leaves; g.pool = c->d_pool; g.adj = c->d_adj; g.Pmat = c->d_Pmat;
     g.bl = c->d_bl; g.br = c->d_br; g.logw = c->d_logw; g.lse = c->d_lse;
@@ -1393,6 +1519,18 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     CHK(launch_check(c, "pg_omega"));
     hipLaunchKernelGGL(pg_G, dim3(R * K), dim3(64), 0, c->stream, g);
     CHK(launch_check(c, "pg_G"));
+    int tw_launches = 0;
+    if (twist) {
+        const size_t J0 = (size_t)((N * (N - 1)) / 2) * c->last_M;
+        hipLaunchKernelGGL(pg_twist_tau, dim3(R * K), dim3(64), J0 * 8, c->stream, g);
+        CHK(launch_check(c, "pg_twist_tau"));
+        hipLaunchKernelGGL(pg_twist_pbar, dim3((unsigned)((c->h_joff[R] + 3) / 4)), dim3(256), 0, c->stream, g);
+        CHK(launch_check(c, "pg_twist_pbar"));
+        hipLaunchKernelGGL(pg_twist_finish, dim3(R * K), dim3(64), 0, c->stream, g);
+        CHK(launch_check(c, "pg_twist_finish"));
+        HIPCHK(c, hipMemsetAsync(c->d_adj, 0, (size_t)R * K * S * 4 * 8, c->stream));   // pg_twist_xsum accumulates, pg_nodes starts from it
+        tw_launches = 4;
+    }
     for (int r = R - 1; r >= 0; --r) {
         hipLaunchKernelGGL(pg_coeff, dim3(K, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r);
         CHK(launch_check(c, "pg_coeff"));
@@ -1402,6 +1540,13 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_leafterm"));
     for (int r = R - 1; r >= 0; --r) {
+        if (twist && ev_chunk0[r + 1] > ev_chunk0[r]) {
+            hipLaunchKernelGGL(pg_twist_xchunks, dim3(ev_chunk0[r + 1] - ev_chunk0[r], cdiv(S, 256)), dim3(256), 0, c->stream, g, r, (int)ev_chunk0[r]);
+            CHK(launch_check(c, "pg_twist_xchunks"));
+            hipLaunchKernelGGL(pg_twist_xsum, dim3(ev_node0[r + 1] - ev_node0[r], cdiv((long)S * 4, 256)), dim3(256), 0, c->stream, g, (int)ev_node0[r], (int)ev_chunk0[r]);
+            CHK(launch_check(c, "pg_twist_xsum"));
+            tw_launches += 2;
+        }
         const int nch = rank_chunk0[r + 1] - rank_chunk0[r];
         if (nch > 0) {
             hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 64), nch), dim3(256), 0, c->stream, g, (int)rank_chunk0[r]);
@@ -1429,7 +1574,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         HIPCHK(c, hipEventElapsedTime(&ms, c->evb0, c->evb1));
         *perf = c->stats;
         perf->sweep_ms = ms;
-        perf->n_launches = 2 * R + 7;
+        perf->n_launches = 2 * R + 7 + tw_launches;
     }
     return PHYLO_OK;
 }

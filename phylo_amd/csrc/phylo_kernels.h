@@ -1915,8 +1915,10 @@ __global__ void pk_twist_tables(const pk_twist_args ta) {
         a.roots_new[(size_t)kg * N + p] = ro[i];
         a.cnt_new[(size_t)kg * N + p] = co[i];
         a.rootll_new[(size_t)kg * N + p] = rl[i];
+        if (a.pos_hist) a.pos_hist[(size_t)kg * N + i] = p;
         ++p;
     }
+    if (a.pos_hist) { a.pos_hist[(size_t)kg * N + il] = -1; a.pos_hist[(size_t)kg * N + ir] = -1; }
     a.roots_new[(size_t)kg * N + p] = N + a.r * a.K + kg;
     a.cnt_new[(size_t)kg * N + p] = co[il] + co[ir];
 }

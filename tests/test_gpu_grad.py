@@ -111,8 +111,71 @@ def test_backward_needs_graph():
         ctx.sweep(1)
         with pytest.raises(_ffi.PhyloError):
             ctx.sweep_backward()
-        with pytest.raises(_ffi.PhyloError):
-            ctx.sweep(1, _ffi.FLAGS_DEFAULT | _ffi.KEEP_GRAPH | _ffi.TWISTING)
+
+
+# ---- the twisted proposal's reverse pass (vncsmc.py:295-416) -----------------------------------------------------
+def _check_twisted(genome, Q, pi, ll, lr, K, M, seed, jc=False):
+    N, S, _ = genome.shape
+    flags = _ffi.FLAGS_DEFAULT | _ffi.TWISTING
+    with _ffi.Context(K, N, S) as ctx:
+        ctx.set_leaves(genome)
+        ctx.set_model(Q, pi, ll, lr, jc69_closed_form=jc)
+        plain = ctx.sweep(seed, flags, M)
+        out = ctx.sweep(seed, flags | _ffi.KEEP_GRAPH, M)
+        for key in ('log_weights', 'log_likelihood', 'ancestors', 'merges', 'left_branches', 'right_branches'):
+            assert np.array_equal(plain[key], out[key]), key
+        assert plain['logZ'] == out['logZ']
+        g = ctx.sweep_backward()
+        g2 = ctx.sweep_backward()
+        for key in ('d_lam_l', 'd_lam_r', 'd_pi', 'd_Q'):
+            assert np.array_equal(g[key], g2[key]), key
+        # a plain keep-graph sweep on the same context afterwards still gives the plain gradient
+        ctx.sweep(seed, _ffi.FLAGS_DEFAULT | _ffi.KEEP_GRAPH)
+        gp = ctx.sweep_backward()
+    # oracle on the device's discrete structure: ancestors, chosen pair (merges) and chosen sub-sample (the branch length)
+    f = G.forward_twisted(genome, Q, pi, ll, lr, K, M, seed)
+    st = f['struct']
+    for r in range(N - 1):
+        if r > 0:
+            st['anc'][r] = out['ancestors'][r - 1].astype(np.int64)
+        pairs = O.pair_list(N - r)
+        b_l = -np.log(st['Ul'][r]) / ll[r]
+        js = np.zeros(K, dtype=np.int64)
+        for k in range(K):
+            t = pairs.index((int(out['merges'][r, k, 0]), int(out['merges'][r, k, 1])))
+            js[k] = t * M + int(np.argmin(np.abs(b_l[k, t * M:(t + 1) * M] - out['left_branches'][r, k])))
+        st['js'][r] = js
+    ref = G.sweep_grad_twisted(genome, Q, pi, ll, lr, K, M, seed, struct=st)
+    assert abs(ref['logZ'] - out['logZ']) < 1e-9 * max(1.0, abs(out['logZ']))
+    for key in ('d_lam_l', 'd_lam_r') + (() if jc else ('d_pi', 'd_Q')):
+        scale = max(np.max(np.abs(ref[key])), 1e-300)
+        err = np.max(np.abs(g[key] - ref[key])) / scale
+        assert err < RTOL, (key, err, g[key], ref[key])
+    rp = G.sweep_grad(genome, Q, pi, ll, lr, K, seed)
+    assert np.max(np.abs(gp['d_lam_l'] - rp['d_lam_l'])) < 1e-6 * max(1.0, np.max(np.abs(rp['d_lam_l'])))
+    return g, ref
+
+
+@pytest.mark.parametrize("M", [1, 3])
+def test_twisted_gradient_small_random_model(M):
+    rng = np.random.default_rng(31)
+    genome = _codes_genome(rng, 6, 24)
+    Q, pi, ll, lr = _model(rng, 6)
+    _check_twisted(genome, Q, pi, ll, lr, K=12, M=M, seed=77)
+
+
+def test_twisted_gradient_two_site_groups_generic_leaves():
+    rng = np.random.default_rng(32)
+    genome = rng.uniform(0.05, 1.0, size=(5, 300, 4))      # two groups of 256 sites in pg_twist_xchunks, ragged
+    Q, pi, ll, lr = _model(rng, 5)
+    _check_twisted(genome, Q, pi, ll, lr, K=40, M=2, seed=5)   # 40 adopters: nodes with more than PG_XCH entries
+
+
+def test_twisted_gradient_jc69_rates_only():
+    genome = load_dataset('primate_data_wang')['genome'][:6, :64]
+    N = genome.shape[0]
+    lam = np.full(N - 1, 10.0)
+    _check_twisted(genome, O.jc_Q(), np.full((1, 4), 0.25), lam, lam, K=16, M=2, seed=8, jc=True)
 
 
 # ---- the training step built on the reverse pass (phylo_amd/train.py, VCSMC.train) ----------------------------
