@@ -97,10 +97,15 @@ def make_optimizer(name, learning_rate):
 class Trainer:
     """One device context sized for a minibatch of sites; `step` = sweep + reverse pass + update."""
 
-    def __init__(self, genome_NxSxA, K, variables, optimizer, batch_sites, device=0, flags=_ffi.FLAGS_DEFAULT):
+    def __init__(self, genome_NxSxA, K, variables, optimizer, batch_sites, device=0, flags=_ffi.FLAGS_DEFAULT, nested=False, M=1):
+        """nested: the twisted proposal of vncsmc.py with M sub-samples per pair; its look-ahead potentials are differentiated
+        like everything else (vncsmc.py:379-416 has no stop_gradient)."""
         self.genome = np.asarray(genome_NxSxA, dtype=np.float64)
         self.v, self.opt = variables, optimizer
         self.flags = (flags | _ffi.KEEP_GRAPH) & ~_ffi.TWISTING
+        if nested:
+            self.flags |= _ffi.TWISTING
+        self.M = int(M) if nested else 1
         N = self.genome.shape[0]
         self.ctx = _ffi.Context(K, N, int(batch_sites), device=device)
         self.last = None
@@ -117,7 +122,7 @@ class Trainer:
             self.ctx.set_leaves(self.genome[:, sites, :])
             self._sites = sites.copy()
         self.ctx.set_model(Q, pi, lam_l, lam_r, jc69_closed_form=self.v.jc)
-        self.ctx.sweep_async(int(seed), self.flags)
+        self.ctx.sweep_async(int(seed), self.flags, self.M)
         out = self.ctx.sweep_fetch(arrays=False)
         raw = self.ctx.sweep_backward()
         raw['forward_ms'] = out['stats']['sweep_ms']

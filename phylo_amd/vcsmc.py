@@ -9,8 +9,8 @@ Differences that are deliberate:
   * jump chains are rebuilt on the host from integer merge records, with the correct per-particle gather
     (the reference's vcsmc.py:306-307 gathers without the row offset, fixed in vncsmc.py);
   * train() takes the reference's optimiser steps (vcsmc.py:488-491, 532-536) with the gradient of the device's
-    reverse pass (phylo_amd/train.py) instead of TensorFlow autodiff; with args.nested the reverse pass of the
-    twisted proposal is not built and train() only evaluates.
+    reverse pass (phylo_amd/train.py) instead of TensorFlow autodiff; with args.nested that is the reverse pass of the
+    twisted proposal (vncsmc.py:568-640), every look-ahead potential differentiated.
 """
 from __future__ import annotations
 
@@ -321,11 +321,9 @@ class VCSMC:
         self.optimizer = train_mod.make_optimizer(getattr(self.args, 'optimizer', ''), self.lr)   # vcsmc.py:488-491
         nested = bool(getattr(self.args, 'nested', False))
         trainer = None
-        if nested:
-            print('nested/twisted proposal: the reverse pass is not built; parameters stay at their initial values')
-        elif len(slices) > 1:
+        if len(slices) > 1:
             trainer = train_mod.Trainer(self.genome_NxSxA, self.K, self.variables, self.optimizer, len(slices[0]),
-                                        device=self._device)
+                                        device=self._device, nested=nested, M=self.M)
         initial = self.sample_phylogenies()
         print('===================\nInitial evaluation of ELBO:', round(initial, 3))
         print('Initial jump chain:')
