@@ -42,6 +42,7 @@ struct pg_twist {
     const int32_t *xchunk_node, *xchunk_beg, *xchunk_cnt;
     const int32_t *xnode_id, *xnode_chunk0, *xnode_nchunks;
     double* tpart;                     // [chunks of one rank event][S][4]
+    const uint32_t* pair_hist;         // [N][N][32] or NULL: sites per code pair of two coded leaves (pk_pair_hist)
 };
 
 struct pg_args {
@@ -75,6 +76,11 @@ struct pg_args {
 };
 
 // ---- small helpers ------------------------------------------------------------------------------
+// The reverse pass has a tolerance, not a bit contract (the build keeps -ffp-contract=off for the forward sweep): its
+// inner products use fused multiply-adds explicitly, which halves their instruction count.
+__device__ __forceinline__ double pg_dot4(double a0, double b0, double a1, double b1, double a2, double b2, double a3, double b3) {
+    return __builtin_fma(a3, b3, __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0)));
+}
 __device__ __forceinline__ double pg_wave_sum(double v) {          // fixed butterfly: same result on every lane
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
@@ -261,6 +267,15 @@ __device__ __forceinline__ double pg_quad(double v) {       // the value held by
     return __hiloint2double(hi, lo);
 }
 
+template <int X>
+__device__ __forceinline__ double pg_quad_sum_step(double v) {   // the value of lane (me ^ X) of my quad, X = 1 or 2
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    constexpr int ctrl = X == 1 ? 0xB1 : 0x4E;                  // quad_perm [1,0,3,2] / [2,3,0,1]
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ void pg_stage_parents(const pg_args& a, int c0, int nc, double (*shP)[32], int* shE, int* shSib) {
     const int e = threadIdx.x >> 5, q = threadIdx.x & 31;
     if (e < nc) {
@@ -283,10 +298,10 @@ __device__ __forceinline__ double pg_parent_quad(const pg_args& a, size_t soff, 
         const double* Psib = shP[e] + (1 - side) * 16;
         const double* Pme = shP[e] + side * 16;
         const double b0 = pg_quad<0>(sb), b1 = pg_quad<1>(sb), b2 = pg_quad<2>(sb), b3 = pg_quad<3>(sb);
-        const double w = ((b0 * Psib[j] + b1 * Psib[4 + j]) + b2 * Psib[8 + j]) + b3 * Psib[12 + j];
+        const double w = pg_dot4(b0, Psib[j], b1, Psib[4 + j], b2, Psib[8 + j], b3, Psib[12 + j]);
         const double t = xp * w;
         const double t0 = pg_quad<0>(t), t1 = pg_quad<1>(t), t2 = pg_quad<2>(t), t3 = pg_quad<3>(t);
-        xb = xb + (((t0 * Pme[j * 4] + t1 * Pme[j * 4 + 1]) + t2 * Pme[j * 4 + 2]) + t3 * Pme[j * 4 + 3]);
+        xb = xb + pg_dot4(t0, Pme[j * 4], t1, Pme[j * 4 + 1], t2, Pme[j * 4 + 2], t3, Pme[j * 4 + 3]);
     }
     return xb;
 }
@@ -364,11 +379,11 @@ __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
         const double x = xs[it];
         const double Lj = Ls[it], Rj = Rs[it];
         const double x0 = pg_quad<0>(x), x1 = pg_quad<1>(x), x2 = pg_quad<2>(x), x3 = pg_quad<3>(x);
-        const double lik = ((p0 * x0 + p1 * x1) + p2 * x2) + p3 * x3;
+        const double lik = pg_dot4(p0, x0, p1, x1, p2, x2, p3, x3);
         const double inv = alpha / lik;
         double xb = pj * inv;
         if (a.twist) xb = xb + orow[soff];                  // what the look-ahead merges of later rank events left (pg_twist_xsum)
-        acc[8] = acc[8] + x * inv;
+        acc[8] = __builtin_fma(x, inv, acc[8]);
         if (hv >= 0) {
             const double* cp = a.cpart + (size_t)hv * row + soff;
             int c = 0;
@@ -384,11 +399,13 @@ __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
         orow[soff] = xb;
         const double L0 = pg_quad<0>(Lj), L1 = pg_quad<1>(Lj), L2 = pg_quad<2>(Lj), L3 = pg_quad<3>(Lj);
         const double R0 = pg_quad<0>(Rj), R1 = pg_quad<1>(Rj), R2 = pg_quad<2>(Rj), R3 = pg_quad<3>(Rj);
-        const double u = ((L0 * Pl[j] + L1 * Pl[4 + j]) + L2 * Pl[8 + j]) + L3 * Pl[12 + j];
-        const double v = ((R0 * Pr[j] + R1 * Pr[4 + j]) + R2 * Pr[8 + j]) + R3 * Pr[12 + j];
+        const double u = pg_dot4(L0, Pl[j], L1, Pl[4 + j], L2, Pl[8 + j], L3, Pl[12 + j]);
+        const double v = pg_dot4(R0, Pr[j], R1, Pr[4 + j], R2, Pr[8 + j], R3, Pr[12 + j]);
         const double tl = xb * v, tr = xb * u;
-        acc[0] = acc[0] + L0 * tl; acc[1] = acc[1] + L1 * tl; acc[2] = acc[2] + L2 * tl; acc[3] = acc[3] + L3 * tl;
-        acc[4] = acc[4] + R0 * tr; acc[5] = acc[5] + R1 * tr; acc[6] = acc[6] + R2 * tr; acc[7] = acc[7] + R3 * tr;
+        acc[0] = __builtin_fma(L0, tl, acc[0]); acc[1] = __builtin_fma(L1, tl, acc[1]);
+        acc[2] = __builtin_fma(L2, tl, acc[2]); acc[3] = __builtin_fma(L3, tl, acc[3]);
+        acc[4] = __builtin_fma(R0, tr, acc[4]); acc[5] = __builtin_fma(R1, tr, acc[5]);
+        acc[6] = __builtin_fma(R2, tr, acc[6]); acc[7] = __builtin_fma(R3, tr, acc[7]);
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {                           // over the 16 quads of the wave, state j stays in lane j
@@ -576,9 +593,37 @@ __device__ __forceinline__ void pg_pair_of(int t, int n, int& il, int& ir) {
     ir = il + 1 + rem;
 }
 
-// one wave per row: sums over sites of  X1^T (g o v),  X2^T (g o u),  y / lik   with u = X1 Pl, v = X2 Pr, y = u o v,
+// One site of a look-ahead merge: acc += w * { X1^T (g o v),  X2^T (g o u),  y / lik }  with u = X1 Pl, v = X2 Pr, y = u o v,
 // lik = pi . y, g = pi / lik  (the factor tau is applied by pg_twist_finish)
+__device__ __forceinline__ void pg_pbar_site(const double (&x1)[4], const double (&x2)[4], const double (&Pl)[16],
+                                             const double (&Pr)[16], const double (&pi)[4], double w, double (&acc)[PG_PART]) {
+    double u[4], v[4], y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u[j] = pg_dot4(x1[0], Pl[j], x1[1], Pl[4 + j], x1[2], Pl[8 + j], x1[3], Pl[12 + j]);
+        v[j] = pg_dot4(x2[0], Pr[j], x2[1], Pr[4 + j], x2[2], Pr[8 + j], x2[3], Pr[12 + j]);
+        y[j] = u[j] * v[j];
+    }
+    const double lik = pg_dot4(pi[0], y[0], pi[1], y[1], pi[2], y[2], pi[3], y[3]);
+    const double inv = w / lik;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double g = pi[j] * inv;
+        const double gv = g * v[j], gu = g * u[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i * 4 + j] = __builtin_fma(x1[i], gv, acc[i * 4 + j]);
+            acc[16 + i * 4 + j] = __builtin_fma(x2[i], gu, acc[16 + i * 4 + j]);
+        }
+        acc[32 + j] = __builtin_fma(y[j], inv, acc[32 + j]);
+    }
+}
+
+// one wave per row (4 rows per workgroup).  Rows of two coded leaves are left to pg_twist_pbar_ll.
+// The 36 sums over the wave's 64 lanes go through LDS, 12 at a time: lane (q, part) adds 16 of the 64 values of sum q.
+#define PG_RED_STRIDE 68               // doubles per value row: the 48 reading lanes spread over all banks
 __global__ __launch_bounds__(256) void pg_twist_pbar(pg_args a) {
+    __shared__ double red[4][12][PG_RED_STRIDE];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t row = (int64_t)blockIdx.x * 4 + wv;
@@ -587,8 +632,10 @@ __global__ __launch_bounds__(256) void pg_twist_pbar(pg_args a) {
     int il, ir;
     pg_pair_of(id.j / a.tw.M, id.n, il, ir);
     const int32_t* ro = a.tw.roots_ad + ((size_t)id.r * a.K + id.k) * a.N;
-    const double* X1 = pg_row(a, ro[il]);
-    const double* X2 = pg_row(a, ro[ir]);
+    const int n1 = ro[il], n2 = ro[ir];
+    if (a.tw.pair_hist && n1 < a.N && n2 < a.N) return;
+    const double* X1 = pg_row(a, n1);
+    const double* X2 = pg_row(a, n2);
     const double* P = a.tw.tw_P + (size_t)row * 32;
     double Pl[16], Pr[16];
 #pragma unroll
@@ -598,85 +645,134 @@ __global__ __launch_bounds__(256) void pg_twist_pbar(pg_args a) {
 #pragma unroll
     for (int i = 0; i < PG_PART; ++i) acc[i] = 0.0;
     for (int s = lane; s < a.S; s += 64) {
-        double x1[4], x2[4], u[4], v[4], y[4];
+        double x1[4], x2[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { x1[i] = X1[(size_t)s * 4 + i]; x2[i] = X2[(size_t)s * 4 + i]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u[j] = ((x1[0] * Pl[j] + x1[1] * Pl[4 + j]) + x1[2] * Pl[8 + j]) + x1[3] * Pl[12 + j];
-            v[j] = ((x2[0] * Pr[j] + x2[1] * Pr[4 + j]) + x2[2] * Pr[8 + j]) + x2[3] * Pr[12 + j];
-            y[j] = u[j] * v[j];
-        }
-        const double lik = ((pi[0] * y[0] + pi[1] * y[1]) + pi[2] * y[2]) + pi[3] * y[3];
-        const double inv = 1.0 / lik;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double g = pi[j] * inv;
-            const double gv = g * v[j], gu = g * u[j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i * 4 + j] = acc[i * 4 + j] + x1[i] * gv;
-                acc[16 + i * 4 + j] = acc[16 + i * 4 + j] + x2[i] * gu;
-            }
-            acc[32 + j] = acc[32 + j] + y[j] * inv;
-        }
+        pg_pbar_site(x1, x2, Pl, Pr, pi, 1.0, acc);
     }
     double* out = a.tw.twpart + (size_t)row * PG_PART;
+    const int q = lane >> 2, part = lane & 3;
 #pragma unroll
-    for (int i = 0; i < PG_PART; ++i) {
-        const double v = pg_wave_sum(acc[i]);
-        if (lane == 0) out[i] = v;
+    for (int b = 0; b < 3; ++b) {                            // a wave's own LDS rows: no workgroup barrier needed
+#pragma unroll
+        for (int i = 0; i < 12; ++i) red[wv][i][lane] = acc[b * 12 + i];
+        __builtin_amdgcn_wave_barrier();
+        double v = 0.0;
+        if (q < 12) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v = v + red[wv][q][part + 4 * i];
+        }
+        v = v + pg_quad_sum_step<1>(v);
+        v = v + pg_quad_sum_step<2>(v);
+        if (q < 12 && part == 0) out[b * 12 + q] = v;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// one wave per (rank event, particle): its J rows -> branch adjoints -> rate terms and the Q adjoint
-__global__ __launch_bounds__(64) void pg_twist_finish(pg_args a) {
-    const int t = blockIdx.x, lane = threadIdx.x;
-    const int r = t / a.K, k = t - r * a.K;
+// rows of two coded leaves: the site terms take one of 25 values, pair_hist holds how many sites take each.  One thread per
+// row of rank event r: grid (ceil(K J_r / 64)), 64 threads
+__global__ __launch_bounds__(64) void pg_twist_pbar_ll(pg_args a, int r) {
+    const int n = a.N - r, M = a.tw.M, J = (n * (n - 1) / 2) * M;
+    const int64_t rel = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (rel >= (int64_t)a.K * J) return;
+    const int k = (int)(rel / J), j = (int)(rel - (int64_t)k * J);
+    int il, ir;
+    pg_pair_of(j / M, n, il, ir);
+    const int32_t* ro = a.tw.roots_ad + ((size_t)r * a.K + k) * a.N;
+    const int n1 = ro[il], n2 = ro[ir];
+    if (n1 >= a.N || n2 >= a.N) return;
+    const size_t row = (size_t)a.tw.joff[r] + (size_t)rel;
+    const double* P = a.tw.tw_P + row * 32;
+    double Pl[16], Pr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { Pl[i] = P[i]; Pr[i] = P[16 + i]; }
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    double acc[PG_PART];
+#pragma unroll
+    for (int i = 0; i < PG_PART; ++i) acc[i] = 0.0;
+    const uint32_t* hist = a.tw.pair_hist + ((size_t)n1 * a.N + n2) * 32;
+#pragma unroll 1
+    for (int c = 0; c < 25; ++c) {
+        const uint32_t cnt = hist[c];
+        if (cnt == 0) continue;
+        const int cl = c / 5, cr = c - cl * 5;
+        double x1[4], x2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x1[i] = (cl == 4 || cl == i) ? 1.0 : 0.0;
+            x2[i] = (cr == 4 || cr == i) ? 1.0 : 0.0;
+        }
+        pg_pbar_site(x1, x2, Pl, Pr, pi, (double)cnt, acc);
+    }
+    double* out = a.tw.twpart + row * PG_PART;
+#pragma unroll
+    for (int i = 0; i < PG_PART; ++i) out[i] = acc[i];
+}
+
+// Rows of rank event r -> branch adjoints -> rate terms, Frechet terms -> Q adjoint, summed per particle.  A workgroup takes
+// KB = max(1, 256 / J_r) particles (their KB J_r rows are contiguous), one thread per row; the 22 results of a row go to LDS and
+// thread (particle, result) adds the particle's J_r rows in order.  grid (ceil(K / KB)), 256 threads, LDS 22 x 256 doubles.
+__global__ __launch_bounds__(256) void pg_twist_finish(pg_args a, int r) {
+    __shared__ double sh[PG_NODEG][256];
     const int n = a.N - r, J = (n * (n - 1) / 2) * a.tw.M;
-    const size_t row0 = (size_t)a.tw.joff[r] + (size_t)k * J;
+    const int KB = J >= 256 ? 1 : 256 / J;
+    const int k0 = blockIdx.x * KB;
+    const int kb = a.K - k0 < KB ? a.K - k0 : KB;            // particles of this workgroup
+    const size_t row0 = (size_t)a.tw.joff[r] + (size_t)k0 * J;
+    const double ll = a.lam_l[r], lr = a.lam_r[r];
     double Q[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) Q[i] = a.Q[i];
-    const double ll = a.lam_l[r], lr = a.lam_r[r];
-    double res[PG_NODEG];
+    double tot[PG_NODEG];                                     // J > 256: a thread keeps the sum of its rows j = tid, tid + 256, ...
 #pragma unroll
-    for (int i = 0; i < PG_NODEG; ++i) res[i] = 0.0;
-    for (int j = lane; j < J; j += 64) {
-        const size_t row = row0 + j;
-        const double tau = a.tw.tau[row];
-        if (tau == 0.0) continue;
-        const double* pp = a.tw.twpart + row * PG_PART;
+    for (int i = 0; i < PG_NODEG; ++i) tot[i] = 0.0;
+    const int nrows = kb * J;
+    for (int t0 = 0; t0 < (J >= 256 ? J : 256); t0 += 256) {
+        const int t = t0 + (int)threadIdx.x;
+        double res[PG_NODEG];
+#pragma unroll
+        for (int i = 0; i < PG_NODEG; ++i) res[i] = 0.0;
+        const size_t row = row0 + t;
+        const double tau = t < nrows ? a.tw.tau[row] : 0.0;
+        if (tau != 0.0) {
+            const double* pp = a.tw.twpart + row * PG_PART;
 #pragma unroll 1
-        for (int side = 0; side < 2; ++side) {
-            double Pm[16], QP[16], pb[16];
+            for (int side = 0; side < 2; ++side) {
+                double Pm[16], QP[16], pb[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { Pm[i] = a.tw.tw_P[row * 32 + side * 16 + i]; pb[i] = tau * pp[side * 16 + i]; }
-            pm_mm4(Q, Pm, QP);
-            double bb = 0.0;
+                for (int i = 0; i < 16; ++i) { Pm[i] = a.tw.tw_P[row * 32 + side * 16 + i]; pb[i] = tau * pp[side * 16 + i]; }
+                pm_mm4(Q, Pm, QP);
+                double bb = 0.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bb = bb + pb[i] * QP[i];
-            const double b = a.tw.tw_b[row * 2 + side];
-            res[side] = res[side] + bb * (-b / (side ? lr : ll));
-            if (!a.jc) {
-                double At[16], Lf[16];
+                for (int i = 0; i < 16; ++i) bb = bb + pb[i] * QP[i];
+                const double b = a.tw.tw_b[row * 2 + side];
+                res[side] = bb * (-b / (side ? lr : ll));
+                if (!a.jc) {
+                    double At[16], Lf[16];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) At[i * 4 + jj] = Q[jj * 4 + i] * b;
-                pg_expm4_frechet(At, pb, Lf);
+                        for (int jj = 0; jj < 4; ++jj) At[i * 4 + jj] = Q[jj * 4 + i] * b;
+                    pg_expm4_frechet(At, pb, Lf);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) res[2 + i] = res[2 + i] + b * Lf[i];
+                    for (int i = 0; i < 16; ++i) res[2 + i] = res[2 + i] + b * Lf[i];
+                }
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) res[18 + q] = tau * pp[32 + q];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) res[18 + q] = res[18 + q] + tau * pp[32 + q];
+        for (int i = 0; i < PG_NODEG; ++i) tot[i] = tot[i] + res[i];
     }
-    double* out = a.tw.twnode + (size_t)t * PG_NODEG;
 #pragma unroll
-    for (int i = 0; i < PG_NODEG; ++i) {
-        const double v = pg_wave_sum(res[i]);
-        if (lane == 0) out[i] = v;
+    for (int i = 0; i < PG_NODEG; ++i) sh[i][threadIdx.x] = tot[i];
+    __syncthreads();
+    const int span = J >= 256 ? 256 : J;                      // LDS entries per particle
+    for (int o = threadIdx.x; o < kb * PG_NODEG; o += 256) {
+        const int kl = o / PG_NODEG, v = o - kl * PG_NODEG;
+        double acc = 0.0;
+        for (int j = 0; j < span; ++j) acc = acc + sh[v][kl * span + j];
+        a.tw.twnode[((size_t)r * a.K + k0 + kl) * PG_NODEG + v] = acc;
     }
 }
 
@@ -709,18 +805,21 @@ __global__ __launch_bounds__(256) void pg_twist_xchunks(pg_args a, int r, int ch
                 const double tau = a.tw.tau[row];
                 const double* Pme = a.tw.tw_P + row * 32 + side * 16;
                 const double* Psb = a.tw.tw_P + row * 32 + (1 - side) * 16;
-                double u[4], v[4];
+                // with z = Pme (pi o v):  lik = x . z  and the contribution (tau (pi o v) / lik) Pme^T = tau z / lik
+                double z[4];
+                {
+                    double pv[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    u[j] = ((x0 * Pme[j] + x1 * Pme[4 + j]) + x2 * Pme[8 + j]) + x3 * Pme[12 + j];
-                    v[j] = ((s0 * Psb[j] + s1 * Psb[4 + j]) + s2 * Psb[8 + j]) + s3 * Psb[12 + j];
+                    for (int j = 0; j < 4; ++j)
+                        pv[j] = pi[j] * pg_dot4(s0, Psb[j], s1, Psb[4 + j], s2, Psb[8 + j], s3, Psb[12 + j]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        z[q] = pg_dot4(pv[0], Pme[q * 4], pv[1], Pme[q * 4 + 1], pv[2], Pme[q * 4 + 2], pv[3], Pme[q * 4 + 3]);
                 }
-                const double lik = ((pi[0] * (u[0] * v[0]) + pi[1] * (u[1] * v[1])) + pi[2] * (u[2] * v[2])) + pi[3] * (u[3] * v[3]);
+                const double lik = pg_dot4(x0, z[0], x1, z[1], x2, z[2], x3, z[3]);
                 const double f = tau / lik;
-                const double t0 = (f * pi[0]) * v[0], t1 = (f * pi[1]) * v[1], t2 = (f * pi[2]) * v[2], t3 = (f * pi[3]) * v[3];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    xb[q] = xb[q] + (((t0 * Pme[q * 4] + t1 * Pme[q * 4 + 1]) + t2 * Pme[q * 4 + 2]) + t3 * Pme[q * 4 + 3]);
+                for (int q = 0; q < 4; ++q) xb[q] = __builtin_fma(f, z[q], xb[q]);
             }
         }
     }

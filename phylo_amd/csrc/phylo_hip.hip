@@ -1504,6 +1504,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         g.tw.xnode_chunk0 = xl; xl += n_xnodes;
         g.tw.xnode_nchunks = xl;
         g.tw.tpart = (double*)d_tpart;
+        g.tw.pair_hist = (c->codes_valid && c->hist_ready) ? c->d_pair_hist : nullptr;
     }
     g.heavy_first = c->d_heavy; g.chunk_beg = c->d_chunk_beg; g.chunk_cnt = c->d_chunk_cnt; g.cpart = (double*)cpart;
     g.leaves = c->d_leaves; g.pool = c->d_pool; g.adj = c->d_adj; g.Pmat = c->d_Pmat;
@@ -1526,10 +1527,22 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         CHK(launch_check(c, "pg_twist_tau"));
         hipLaunchKernelGGL(pg_twist_pbar, dim3((unsigned)((c->h_joff[R] + 3) / 4)), dim3(256), 0, c->stream, g);
         CHK(launch_check(c, "pg_twist_pbar"));
-        hipLaunchKernelGGL(pg_twist_finish, dim3(R * K), dim3(64), 0, c->stream, g);
-        CHK(launch_check(c, "pg_twist_finish"));
+        if (g.tw.pair_hist)
+            for (int r = 0; r < R; ++r) {
+                const long rows_r = (long)(c->h_joff[r + 1] - c->h_joff[r]);
+                hipLaunchKernelGGL(pg_twist_pbar_ll, dim3(cdiv(rows_r, 64)), dim3(64), 0, c->stream, g, r);
+                CHK(launch_check(c, "pg_twist_pbar_ll"));
+                ++tw_launches;
+            }
+        for (int r = 0; r < R; ++r) {
+            const int Jr = (((N - r) * (N - r - 1)) / 2) * c->last_M;
+            const int KB = Jr >= 256 ? 1 : 256 / Jr;
+            hipLaunchKernelGGL(pg_twist_finish, dim3(cdiv(K, KB)), dim3(256), 0, c->stream, g, r);
+            CHK(launch_check(c, "pg_twist_finish"));
+            ++tw_launches;
+        }
         HIPCHK(c, hipMemsetAsync(c->d_adj, 0, (size_t)R * K * S * 4 * 8, c->stream));   // pg_twist_xsum accumulates, pg_nodes starts from it
-        tw_launches = 4;
+        tw_launches += 3;
     }
     for (int r = R - 1; r >= 0; --r) {
         hipLaunchKernelGGL(pg_coeff, dim3(K, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r);

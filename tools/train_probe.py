@@ -18,13 +18,15 @@ ap.add_argument('--K', type=int, default=2048)
 ap.add_argument('--sites', type=int, default=0)
 ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--jcmodel', action='store_true')
+ap.add_argument('--nested', action='store_true')
+ap.add_argument('--M', type=int, default=1)
 a = ap.parse_args()
 
 genome = load_dataset(a.dataset)['genome']
 N, S, _ = genome.shape
 B = a.sites or S
 v = T.Variables(N, np.log(10.0), a.jcmodel)
-tr = T.Trainer(genome, a.K, v, T.make_optimizer('Adam', 0.01), B)
+tr = T.Trainer(genome, a.K, v, T.make_optimizer('Adam', 0.01), B, nested=a.nested, M=a.M)
 rng = np.random.default_rng(0)
 fw, bw, wall = [], [], []
 for i in range(a.steps + 3):
@@ -36,7 +38,7 @@ for i in range(a.steps + 3):
         fw.append(tr.last['raw']['forward_ms'])
         bw.append(tr.last['raw']['backward_ms'])
         wall.append((t1 - t0) * 1e3)
-print(json.dumps({'dataset': a.dataset, 'K': a.K, 'N': N, 'sites': B, 'steps': a.steps,
+print(json.dumps({'dataset': a.dataset, 'nested': a.nested, 'M': a.M, 'K': a.K, 'N': N, 'sites': B, 'steps': a.steps,
                   'forward_ms': float(np.mean(fw)), 'backward_ms': float(np.mean(bw)), 'step_wall_ms': float(np.mean(wall)),
                   'step_wall_ms_min': float(np.min(wall)), 'last_logZ': tr.last['logZ']}))
 tr.close()
