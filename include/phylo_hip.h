@@ -54,7 +54,8 @@ enum {
                                           The nodes of the LAST rank event are never read by a merge and are not stored
                                           either (phylo_sweep_node writes them on demand) unless this flag is set */
     PHYLO_KEEP_GRAPH = 1u << 4,        /* keep what phylo_sweep_backward needs (root-table history of every rank
-                                          event, every node); one GPU, plain proposal; implies PHYLO_EAGER_NODES */
+                                          event, every node; with PHYLO_TWISTING also every sub-sample's branch lengths,
+                                          transition matrices and potential); one GPU; implies PHYLO_EAGER_NODES */
     PHYLO_ONE_LAUNCH = 1u << 5,        /* run the whole sweep as ONE launch of resident workgroups (phylo_persist.h) where that
                                           form applies (phylo_sweep_async / phylo_sweep_batch_async on one GPU, plain proposal,
                                           N <= 32, small nodes) instead of launches per rank event (scan, bookkeeping,
@@ -182,7 +183,9 @@ int phylo_sweep_node(phylo_ctx* ctx, int r, int k, double* out_Sx4);
  * respect to the raw model quantities, d_lam_l[N-1], d_lam_r[N-1], d_pi[4], d_Q[16] (row-major).
  * Replaces the TensorFlow autodiff behind optimizer.minimize(self.cost), vcsmc.py:488-491,534 (cost = -logZ):
  * resampling indices, pair picks and gather indices are constants, branch lengths are reparameterised samples
- * b = -log(U)/lambda (vcsmc.py:353-356), everything else is differentiated.  With jc69_closed_form the Q and pi
+ * b = -log(U)/lambda (vcsmc.py:353-356), everything else is differentiated.  After a twisted sweep
+ * (PHYLO_TWISTING | PHYLO_KEEP_GRAPH) that includes the look-ahead potentials of every (pair, sub-sample), whose normalised
+ * value of the chosen one enters the weight (vncsmc.py:399-401, 491; no stop_gradient there).  With jc69_closed_form the Q and pi
  * outputs are still produced (the reference holds them constant; the host ignores them).
  * perf (may be NULL): sweep_ms = device time of the reverse pass. */
 int phylo_sweep_backward(phylo_ctx* ctx, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q,
