@@ -1598,7 +1598,21 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_ran
     cols[tid] = pm_lp_finish(col);
     __syncthreads();
     const double tot = pk_block_canon_sum(cols[tid], sh4);
-    if (tid == 0) pk_merge_epilogue(a, k, kg, tot);
+    if (tid == 0) {
+        // the epilogue's pointers are read from the kernel-argument segment HERE: taken from `a` they are loaded at the top of the
+        // kernel and stay live in scalar registers through the row loops, next to the 64 registers of P_l and P_r
+        typedef __attribute__((address_space(4))) const pk_rank_args pk_kernarg;
+        pk_kernarg* ka = (pk_kernarg*)__builtin_amdgcn_kernarg_segment_ptr();
+        const double* ax = ka->aux + (size_t)k * PK_AUX;
+        const double fl = ax[AUX_SUM_REM] + tot;
+        const double ll = ((fl + ax[AUX_FPRIOR]) + ax[AUX_LPRIOR]) + ax[AUX_RPRIOR];
+        const double lw = (((ll - ax[AUX_LL_TILDE]) - ax[AUX_PAREN]) + ax[AUX_LOGV]) - ax[AUX_Q];
+        const int N = ka->N, r = ka->r, K = ka->K;
+        ka->nodell[N + r * K + kg] = tot;
+        ka->rootll_new[(size_t)kg * N + (ka->n - 2)] = tot;
+        ka->ll_r[kg] = ll;
+        ka->logw_r[kg] = lw;
+    }
 }
 
 #define PK_TWIST_LDS_ROWS 8              // (pair, sub-sample) rows staged and reduced per pass

@@ -246,3 +246,41 @@ def test_one_launch_is_deterministic_with_contexts_in_flight():
     assert ref[100][0] == CO.sweep(g, Q, PI, lam, lam, 2048, 100)['logZ']
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("flags", FORMS, ids=FORM_IDS)
+@pytest.mark.parametrize("K", [64, 1000, 4096])
+def test_flat_weights_most_nodes_are_adopted(K, flags):
+    """The opposite of real data's weight degeneracy: all-gap rows (every site likelihood is 1, weights differ only through the
+    priors), so most particles are adopted and most nodes of a rank event are written (lazy nodes: nearly every node is
+    materialised, and many merges read a node written one launch earlier).  Bit-exact against the oracle, nodes included."""
+    N, S = 9, 333
+    g = np.ones((N, S, 4))
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    ctx = ctx_for(g, K, Q)
+    for seed in (2, 11):
+        out = ctx.sweep(seed, flags=flags)
+        ref = CO.sweep(g, Q, PI, lam, lam, K, seed, want_nodes=(K <= 64))
+        check(out, ref, "flat K=%d seed %d" % (K, seed))
+        assert len(np.unique(out['ancestors'][0])) > K // 3        # the regime this test is about
+        if K <= 64:
+            for r in range(N - 1):
+                for k in (0, K // 2, K - 1):
+                    assert same_bits(ctx.sweep_node(r, k), ref['nodes'][r, k]), "node (%d,%d)" % (r, k)
+    ctx.close()
+
+
+@pytest.mark.parametrize("flags", FORMS, ids=FORM_IDS)
+def test_generic_leaf_row_no_codes(flags):
+    """One leaf row that is neither one-hot nor all-ones: no leaf codes, every child goes through the row loads."""
+    g = load_dataset('primate_data')['genome'][:8, :300].copy()
+    g[2, 11] = [0.25, 0.5, 0.125, 0.125]
+    N = 8
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 3.0)
+    ctx = ctx_for(g, 512, Q)
+    ctx.set_model(Q, PI, lam, lam)
+    for seed in (0, 1, 2):
+        check(ctx.sweep(seed, flags=flags), CO.sweep(g, Q, PI, lam, lam, 512, seed), "generic leaves seed %d" % seed)
+    ctx.close()
