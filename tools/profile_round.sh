@@ -26,6 +26,7 @@ run trace_twist rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/tr
 run pmc_twist   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d "$OUT/pmc_twist" -- python3 "$B" --twisting --M 1 --steps 3 --warmup 1 --streams 1 $COMMON
 run trace_ds1   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_ds1" -- python3 "$B" --dataset hohna_data_1 --n_particles 4096 --steps 6 --warmup 1 --streams 1 $COMMON
 run trace_train rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_train" -- python3 "$REPO/tools/train_probe.py" --steps 10
+run trace_nested rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_nested" -- python3 "$REPO/tools/train_probe.py" --steps 10 --nested --M 1
 fi
 PROFILES_OUT=$REPO/gpurun_out/profiles_$TAG python3 "$REPO/tools/summarize_profiles.py" "$TAG" > "$OUT/summary.log" 2>&1
 # the raw traces are large (gpurun copies back at most 64 MiB): keep the summaries only

@@ -33,7 +33,8 @@ RUNS = [("default", "`python bench.py --steps 30 --warmup 3` (10 sweeps per laun
         ("1stream", "`--streams 1 --batch 1`: one sweep at a time, launches per rank event"),
         ("onelaunch", "`--streams 1 --batch 1 --one-launch`: single sweeps (t_sweep section) in the one-launch form, phylo_persist.h"),
         ("twist", "`--twisting --M 1 --streams 1`"), ("ds1", "`--dataset hohna_data_1 --n_particles 4096 --streams 1`"),
-        ("train", "`python tools/train_probe.py --steps 10` (sweep with the graph kept + reverse pass)")]
+        ("train", "`python tools/train_probe.py --steps 10` (sweep with the graph kept + reverse pass)"),
+        ("nested", "`python tools/train_probe.py --steps 10 --nested --M 1` (twisted sweep with the graph kept + its reverse pass)")]
 lines = ["# rocprofv3 summary, round %s" % tag, "",
          "Workload: primate.p N=12 S=898, GTR-init, K=2048 per sweep.  All bench commands carry",
          "`--no-cpu-baseline --no-parity --min-timed-ms 0`.  Raw tables: `%s_kernel_stats_*.csv`; counters: `%s_merge_pmc.json`." % (tag, tag), ""]
