@@ -34,6 +34,7 @@ struct sweep_run {                       // a sweep being issued rank event by r
     uint32_t flags = 0;
     int M = 1, launches = 0, next_r = 0;
     bool twist = false, graph = false, lazy = false, timek = false, fuse_scan = false, active = false, local_book = false;
+    bool book_mat = false;                 // bookkeeping and the writes of the adopted nodes share one launch (pk_rank_book_mat)
     int G = 1;                             // independent sweeps batched in this context (phylo_sweep_batch_async)
     bool final_missing = false;            // the last rank event's nodes were not stored
     int a_done_r = -1;                     // rank event whose first half (sweep_step_a) has been issued
@@ -43,7 +44,7 @@ struct sweep_run {                       // a sweep being issued rank event by r
 struct env_switches {
     bool eager_nodes = false, rehearse_sharded = false, replicated_book = false, fuse_scan = false,
          book_one_per_wave = false, merge_pair_form = false, no_leaf_codes = false, one_launch = false,
-         persist_stamps = false;
+         persist_stamps = false, separate_materialise = false;
     int persist_wgs = 0;                 // PHYLO_PERSIST_WGS: resident workgroups of the one-launch sweep (0 = default)
     int persist_nt = 256;                // PHYLO_PERSIST_NT: threads per workgroup of the one-launch sweep (256 or 512)
     void read() {
@@ -56,6 +57,7 @@ struct env_switches {
         no_leaf_codes = getenv("PHYLO_NO_LEAF_CODES") != nullptr;
         one_launch = getenv("PHYLO_ONE_LAUNCH") != nullptr;
         persist_stamps = getenv("PHYLO_PERSIST_STAMPS") != nullptr;
+        separate_materialise = getenv("PHYLO_SEPARATE_MATERIALISE") != nullptr;
         const char* w = getenv("PHYLO_PERSIST_WGS");
         persist_wgs = w ? atoi(w) : 0;
         const char* t = getenv("PHYLO_PERSIST_NT");
@@ -791,11 +793,18 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     c->swept = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     if (lazy) HIPCHK(c, hipMemsetAsync(c->d_mark, 0, (((size_t)R * K + R + 3) & ~(size_t)3) * sizeof(unsigned int), c->stream));
+    // one sweep alone on one GPU with lazy nodes: the adopted nodes are written in the bookkeeping launch (pk_rank_book_mat), found
+    // by the resampling draws, which pk_sweep_draws then leaves in d_rdraw.  Batched sweeps keep the separate launch (measured:
+    // 2.45e11 against 2.64e11 units/s with the grouped form of the combined launch).
+    const bool book_mat = lazy && c->world == 1 && c->comm.transport == 0 && !fuse_scan && N <= 32 && S <= 4096 && G == 1 && Kl <= 8192 &&
+                          !c->env.separate_materialise && !c->env.book_one_per_wave;
+    if (book_mat && !c->d_rdraw) CHK(dalloc(c, &c->d_rdraw, (size_t)R * K));
     if (!twist) {
         if (G > 1) HIPCHK(c, hipMemcpyAsync(c->d_group_seeds, group_seeds, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(pk_sweep_draws, dim3(cdiv(2L * R * Kl, 64)), dim3(64), 0, c->stream, c->d_Q, c->d_lam_l, c->d_lam_r,
                            c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat, K / G,
-                           G > 1 ? (const uint64_t*)c->d_group_seeds : (const uint64_t*)nullptr);
+                           G > 1 ? (const uint64_t*)c->d_group_seeds : (const uint64_t*)nullptr,
+                           book_mat ? c->d_rdraw : (unsigned long long*)nullptr);
         CHK(launch_check(c, "pk_sweep_draws"));
     }
     hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream,
@@ -806,6 +815,7 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     c->run = sweep_run{};
     c->run.seed = seed; c->run.flags = flags; c->run.M = M;
     c->run.twist = twist; c->run.graph = graph; c->run.lazy = lazy; c->run.timek = timek; c->run.fuse_scan = fuse_scan;
+    c->run.book_mat = book_mat;
     c->run.launches = launches; c->run.next_r = 0; c->run.active = true;
     c->run.G = G;
     return PHYLO_OK;
@@ -878,8 +888,8 @@ static int sweep_persistent(phylo_ctx* c, uint64_t seed, uint32_t flags, const u
         CHK(refresh_leaf_ll(c));
     }
     const int N = c->N, K = c->K, S = c->S, R = N - 1, Kg = K / G;
-    if (!c->d_rdraw) {
-        CHK(dalloc(c, &c->d_rdraw, (size_t)R * K));
+    if (!c->d_rdraw) CHK(dalloc(c, &c->d_rdraw, (size_t)R * K));       // (the launch path's pk_rank_book_mat shares this buffer)
+    if (!c->d_pctr) {
         CHK(dalloc(c, &c->d_pctr, (size_t)PK_MAX_GROUPS * PP_CTR_STRIDE));
         HIPCHK(c, hipMemsetAsync(c->d_pctr, 0, (size_t)PK_MAX_GROUPS * PP_CTR_STRIDE * 8, c->stream));
         c->pctr_base = 0;
@@ -1058,6 +1068,19 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             hipLaunchKernelGGL(pk_twist_tables, dim3(cdiv(K, 128)), dim3(128), 0, c->stream, ta);
             CHK(launch_check(c, "pk_twist_tables"));
             launches += 5;
+        } else if (c->run.book_mat && r > 0) {
+            b.rdraw = c->d_rdraw + (size_t)r * K;
+            const int grouped = Kl > 8192 ? 1 : 0;
+            const int mat_blocks = grouped ? K / PK_MAT_GROUP : K;
+            if (N <= 16) {
+                const int bb = cdiv(K, PK_COLS / 16);
+                hipLaunchKernelGGL(pk_rank_book_mat<16>, dim3(bb + mat_blocks), dim3(PK_COLS), lds * (PK_COLS / 16), c->stream, b, bb, grouped);
+            } else {
+                const int bb = cdiv(K, PK_COLS / 32);
+                hipLaunchKernelGGL(pk_rank_book_mat<32>, dim3(bb + mat_blocks), dim3(PK_COLS), lds * (PK_COLS / 32), c->stream, b, bb, grouped);
+            }
+            CHK(launch_check(c, "pk_rank_book_mat"));
+            ++launches;
         } else if (r > 0 && fuse_scan) {
             // scan of log w_{r-1} and the bookkeeping of rank event r in one launch
             b.scan_logw = c->d_logw + (size_t)(r - 1) * K;
@@ -1091,7 +1114,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             CHK(launch_check(c, "pk_rank_book"));
             ++launches;
         }
-        if (lazy && r > 0 && !(c->run.local_book && !twist)) {   // (sharded with owner-held tables: done in sweep_step_a)
+        if (lazy && r > 0 && !(c->run.local_book && !twist) && !c->run.book_mat) {   // (sharded with owner-held tables: done in sweep_step_a)
             // few nodes are marked, almost every workgroup leaves at once: one workgroup per particle for small nodes (a quarter
             // of the empty workgroups), site tiles for large ones (a marked node is then not limited to one CU's bandwidth)
             // large launches of small nodes (batched sweeps): dispatching one workgroup per particle costs more than the few writes

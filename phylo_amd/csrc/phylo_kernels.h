@@ -101,13 +101,18 @@ __global__ __launch_bounds__(64) void pk_expm_batched(const double* __restrict__
 __global__ __launch_bounds__(64) void pk_sweep_draws(const double* __restrict__ Q, const double* __restrict__ lam_l,
                                                      const double* __restrict__ lam_r, int jc, uint64_t seed, int R, int K,
                                                      int k0, double* __restrict__ bl, double* __restrict__ br,
-                                                     double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds) {
+                                                     double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds,
+                                                     unsigned long long* __restrict__ rdraw /*[R][K] or NULL: resampling draws*/) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * R * K) return;
     const int side = t & 1, i = t >> 1;
     const int r = i / K, k = i - r * K;
     int kp = k0 + k;                                      // particle index of the RNG contract
     if (group_seeds) { const int g = kp / Kg; seed = group_seeds[g]; kp -= g * Kg; }
+    if (rdraw && side == 0 && r > 0) {                    // the 64-bit draw the index search of rank event r scales by the cdf total
+        const pm_u32x4 d = pm_philox4x32((uint32_t)kp, (uint32_t)r, PM_STREAM_RESAMPLE, 0u, seed);
+        rdraw[i] = ((unsigned long long)d.y << 32) | d.x;
+    }
     const pm_u32x4 x = pm_philox4x32((uint32_t)kp, (uint32_t)r, PM_STREAM_BRANCH, 0u, seed);
     const double b = side ? (-pm_log(pm_unit_oc(x.z, x.w))) / lam_r[r] : (-pm_log(pm_unit_oc(x.x, x.y))) / lam_l[r];
     (side ? br : bl)[i] = b;
@@ -502,6 +507,7 @@ struct pk_rank_args {
     int Kg;
     const uint64_t* group_seeds;                          // [G] or NULL (use `seed`)
     int no_store;                                         // the merge does not store its node (last rank event: never read again)
+    const unsigned long long* rdraw;                      // [K] 64-bit resampling draws of this rank event (pk_rank_book_mat)
 };
 
 // LDS carve of the bookkeeping prologue (arrays of length N rounded up to a multiple of 4)
@@ -995,6 +1001,80 @@ __global__ __launch_bounds__(PK_COLS) void pk_materialize_rank(const pk_rank_arg
 // every node of rank event rho, unconditionally (the nodes of the last rank event are not stored by the sweep)
 __global__ __launch_bounds__(PK_COLS) void pk_materialize_all(const pk_rank_args a, int rho) {
     pk_materialize_node(a, rho, a.k0 + blockIdx.x, threadIdx.x, PK_COLS, 0, a.S);
+}
+
+// Bookkeeping AND the writes of the adopted nodes in one launch (one GPU, lazy nodes, N <= 32).  Launched one after the other
+// they are two dependent launches at their latency floors (7.4 + 5.1 us at K = 2048): pk_materialize_adopted waits for the marks
+// the bookkeeping leaves.  But whether particle k was adopted does not need the bookkeeping: with the K draws of this rank event
+// (written once per sweep by pk_sweep_draws), thr = mulhi64(draw, cdf total) is what the index search compares the cdf with, and k
+// is adopted iff some thr lies in [cdf[k-1], cdf[k]).
+// So workgroups [0, book_blocks) do the packed bookkeeping (256 / LP particles each) while workgroups behind them test the
+// thresholds and write node (r-1, k) where needed:
+//   per_particle: one workgroup per particle (K / 256 thresholds per thread, most workgroups leave after the test);
+//   grouped (large batched launches): one workgroup per 64 particles, hits located in the group's 64 cdf values, written in turn.
+// Nodes written here are read by the merge launch that follows, never inside this launch.  Same values, same bits.
+__device__ __forceinline__ void pk_mat_by_thresholds(const pk_rank_args& a, int kg) {
+    const int tid = threadIdx.x;
+    const int grp = a.group_seeds ? kg / a.Kg : 0, gbase = grp * a.Kg, Kg = a.group_seeds ? a.Kg : a.K, kin = kg - gbase;
+    const unsigned long long lo = kin > 0 ? a.cdf[gbase + kin - 1] : 0ull, hi = a.cdf[gbase + kin], total = a.cdf[gbase + Kg - 1];
+    unsigned int hit = 0u;                                // no branch around the loads: they all travel together
+    #pragma unroll 4
+    for (int i = tid; i < Kg; i += PK_COLS) {
+        const unsigned long long t = pm_mulhi64(a.rdraw[gbase + i], total);
+        hit |= (unsigned int)(t >= lo) & (unsigned int)(t < hi);
+    }
+    if (!__syncthreads_or((int)hit)) return;
+    pk_materialize_node(a, a.r - 1, kg, tid, PK_COLS, 0, a.S);
+}
+__device__ __forceinline__ void pk_mat_by_thresholds_grouped(const pk_rank_args& a, int k0) {   // particles k0 .. k0 + 63, one group
+    __shared__ unsigned long long gcdf[PK_MAT_GROUP];
+    __shared__ unsigned int maskw[2];
+    const int tid = threadIdx.x;
+    const int grp = a.group_seeds ? k0 / a.Kg : 0, gbase = grp * a.Kg, Kg = a.group_seeds ? a.Kg : a.K, kin0 = k0 - gbase;
+    const int cnt = Kg - kin0 < PK_MAT_GROUP ? Kg - kin0 : PK_MAT_GROUP;
+    if (tid < PK_MAT_GROUP) gcdf[tid] = a.cdf[gbase + kin0 + (tid < cnt ? tid : cnt - 1)];
+    if (tid < 2) maskw[tid] = 0u;
+    const unsigned long long lo = kin0 > 0 ? a.cdf[gbase + kin0 - 1] : 0ull, total = a.cdf[gbase + Kg - 1];
+    __syncthreads();
+    const unsigned long long hi = gcdf[cnt - 1];
+    #pragma unroll 4
+    for (int i = tid; i < Kg; i += PK_COLS) {
+        const unsigned long long t = pm_mulhi64(a.rdraw[gbase + i], total);
+        if (t >= lo && t < hi) {                          // rare (64 of Kg draws on average): first j with gcdf[j] > t
+            int j = 0;
+            while (gcdf[j] <= t) ++j;
+            atomicOr(&maskw[j >> 5], 1u << (j & 31));     // integer LDS atomic: the result does not depend on the order
+        }
+    }
+    __syncthreads();
+    unsigned long long todo = ((unsigned long long)maskw[1] << 32) | maskw[0];
+    while (todo) {                                        // workgroup-uniform
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        pk_materialize_node(a, a.r - 1, k0 + j, tid, PK_COLS, 0, a.S);
+    }
+}
+
+template <int LP>
+__global__ __launch_bounds__(PK_COLS) void pk_rank_book_mat(const pk_rank_args a, int book_blocks, int grouped) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= book_blocks) {
+        const int b = (int)blockIdx.x - book_blocks;
+        if (grouped) pk_mat_by_thresholds_grouped(a, b * PK_MAT_GROUP);
+        else pk_mat_by_thresholds(a, b);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, sub = tid / LP, sl = tid & (LP - 1);
+    int idx = blockIdx.x * (PK_COLS / LP) + sub;
+    if (idx >= a.K) idx = a.K - 1;              // a spare group repeats the last particle: identical values, identical writes
+    const int kg = idx;                         // one GPU: every particle is local
+    const pk_book_lds L = pk_book_carve(smem + (size_t)sub * pk_book_lds_bytes(a.N), a.N);
+    pk_book_packed<LP>(a, kg, true, L, sl, lane);
+    if (sl < PK_AUX + 2) {
+        if (sl < PK_AUX) a.aux[(size_t)kg * PK_AUX + sl] = L.aux[sl];
+        else a.child[kg * 2 + (sl - PK_AUX)] = L.misc[sl - PK_AUX];
+    }
+    if (a.r > 0 && sl == 0) a.mark[(size_t)(a.r - 1) * a.K + L.misc[3]] = 1u;   // the marks stay (phylo_sweep_node reads them)
 }
 
 // Bookkeeping kernel: one 64-thread workgroup (one wave) per GLOBAL particle.  Particles of this rank's
