@@ -34,6 +34,7 @@ struct sweep_run {                       // a sweep being issued rank event by r
     uint32_t flags = 0;
     int M = 1, launches = 0, next_r = 0;
     bool twist = false, graph = false, lazy = false, timek = false, fuse_scan = false, active = false, local_book = false;
+    bool logz_done = false;                // the last scan summed the log-normalisers (no pk_logz_total launch)
     bool book_mat = false;                 // bookkeeping and the writes of the adopted nodes share one launch (pk_rank_book_mat)
     int G = 1;                             // independent sweeps batched in this context (phylo_sweep_batch_async)
     bool final_missing = false;            // the last rank event's nodes were not stored
@@ -362,13 +363,13 @@ int ensure_graph_state(phylo_ctx* c) {
 }
 
 // resampling scan of G groups of Kg log-weights: the LDS form when a group fits (phylo_persist.h), else pk_resample_scan
-int launch_scan(phylo_ctx* c, const double* logw, int Kg, int G, uint64_t* cdf, double* lse, int lse_stride) {
+int launch_scan(phylo_ctx* c, const double* logw, int Kg, int G, uint64_t* cdf, double* lse, int lse_stride, int logz_R = 0) {
     if (Kg <= 4096) {
-        hipLaunchKernelGGL(pp_resample_scan<512>, dim3(G), dim3(512), pp_resample_scan_lds(Kg), c->stream, logw, Kg, cdf, lse, lse_stride);
+        hipLaunchKernelGGL(pp_resample_scan<512>, dim3(G), dim3(512), pp_resample_scan_lds(Kg), c->stream, logw, Kg, cdf, lse, lse_stride, logz_R);
         return launch_check(c, "pp_resample_scan");
     }
     if (Kg <= PP_SCAN_KERNEL_MAX_KG) {      // large groups (the replicated scan of a sharded sweep): 16 waves, 128 KiB of LDS
-        hipLaunchKernelGGL(pp_resample_scan<1024>, dim3(G), dim3(1024), pp_resample_scan_lds(Kg), c->stream, logw, Kg, cdf, lse, lse_stride);
+        hipLaunchKernelGGL(pp_resample_scan<1024>, dim3(G), dim3(1024), pp_resample_scan_lds(Kg), c->stream, logw, Kg, cdf, lse, lse_stride, logz_R);
         return launch_check(c, "pp_resample_scan");
     }
     if (G > 1) hipLaunchKernelGGL(pk_resample_scan_groups, dim3(G), dim3(PK_COLS), pk_scan_lds_bytes(Kg), c->stream, logw, Kg, cdf, lse, lse_stride);
@@ -792,26 +793,39 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     const bool fuse_scan = !twist && !graph && G == 1 && c->env.fuse_scan;   // opt-in: measured neutral alone, -4 % with 3 sweeps in flight
     c->swept = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    if (lazy) HIPCHK(c, hipMemsetAsync(c->d_mark, 0, (((size_t)R * K + R + 3) & ~(size_t)3) * sizeof(unsigned int), c->stream));
     // one sweep alone on one GPU with lazy nodes: the adopted nodes are written in the bookkeeping launch (pk_rank_book_mat), found
     // by the resampling draws, which pk_sweep_draws then leaves in d_rdraw.  Batched sweeps keep the separate launch (measured:
     // 2.45e11 against 2.64e11 units/s with the grouped form of the combined launch).
     const bool book_mat = lazy && c->world == 1 && c->comm.transport == 0 && !fuse_scan && N <= 32 && S <= 4096 && G == 1 && Kl <= 8192 &&
                           !c->env.separate_materialise && !c->env.book_one_per_wave;
     if (book_mat && !c->d_rdraw) CHK(dalloc(c, &c->d_rdraw, (size_t)R * K));
-    if (!twist) {
+    const size_t mark_words = ((size_t)R * K + R + 3) & ~(size_t)3;
+    int32_t* t_roots = graph ? c->d_hroots : c->d_roots[0];
+    int32_t* t_cnt = graph ? c->d_hcnt : c->d_cnt[0];
+    double* t_rootll = graph ? c->d_hrootll : c->d_rootll[0];
+    if (!twist) {                                          // draws, initial tables and cleared marks: one launch
         if (G > 1) HIPCHK(c, hipMemcpyAsync(c->d_group_seeds, group_seeds, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(pk_sweep_draws, dim3(cdiv(2L * R * Kl, 64)), dim3(64), 0, c->stream, c->d_Q, c->d_lam_l, c->d_lam_r,
-                           c->jc, seed, R, Kl, c->k0, c->d_bl, c->d_br, c->d_Pmat, K / G,
-                           G > 1 ? (const uint64_t*)c->d_group_seeds : (const uint64_t*)nullptr,
-                           book_mat ? c->d_rdraw : (unsigned long long*)nullptr);
-        CHK(launch_check(c, "pk_sweep_draws"));
+        pk_prologue_args pa{};
+        pa.Q = c->d_Q; pa.lam_l = c->d_lam_l; pa.lam_r = c->d_lam_r; pa.jc = c->jc; pa.seed = seed; pa.R = R; pa.Kloc = Kl; pa.k0 = c->k0;
+        pa.bl = c->d_bl; pa.br = c->d_br; pa.Pmat = c->d_Pmat; pa.Kg = K / G;
+        pa.group_seeds = G > 1 ? (const uint64_t*)c->d_group_seeds : (const uint64_t*)nullptr;
+        pa.rdraw = book_mat ? c->d_rdraw : (unsigned long long*)nullptr;
+        pa.roots = t_roots; pa.cnt = t_cnt; pa.rootll = t_rootll; pa.nodell = c->d_nodell; pa.K = K; pa.N = N;
+        pa.mark = lazy ? c->d_mark : (unsigned int*)nullptr;
+        pa.mark_words = lazy ? (unsigned int)mark_words : 0u;
+        pa.draw_blocks = cdiv(2L * R * Kl, 64);
+        pa.init_blocks = cdiv((long)K * N, 256);
+        const int mark_blocks = lazy ? cdiv((long)mark_words, 256) : 0;
+        hipLaunchKernelGGL(pk_sweep_prologue, dim3(pa.draw_blocks + pa.init_blocks + mark_blocks), dim3(64), 0, c->stream, pa);
+        CHK(launch_check(c, "pk_sweep_prologue"));
+        launches += 1;
+    } else {
+        if (lazy) HIPCHK(c, hipMemsetAsync(c->d_mark, 0, mark_words * sizeof(unsigned int), c->stream));
+        hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream, t_roots, t_cnt, t_rootll,
+                           (const double*)c->d_nodell, K, N);
+        launches += 1;
     }
-    hipLaunchKernelGGL(pk_init_tables, dim3(cdiv((long)K * N, 256)), dim3(256), 0, c->stream,
-                       graph ? c->d_hroots : c->d_roots[0], graph ? c->d_hcnt : c->d_cnt[0],
-                       graph ? c->d_hrootll : c->d_rootll[0], (const double*)c->d_nodell, K, N);
     CHK(launch_check(c, "pk_init_tables"));
-    launches += 2;
     c->run = sweep_run{};
     c->run.seed = seed; c->run.flags = flags; c->run.M = M;
     c->run.twist = twist; c->run.graph = graph; c->run.lazy = lazy; c->run.timek = timek; c->run.fuse_scan = fuse_scan;
@@ -1158,12 +1172,16 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                 }
             }
             if (G > 1) {                                       // one scan workgroup per batched sweep
+                const bool fold = r + 1 == R && Kg <= PP_SCAN_KERNEL_MAX_KG;   // the last scan also sums the log-normalisers
                 CHK(launch_scan(c, (const double*)(c->d_logw + (size_t)r * K), Kg, G, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
-                                c->d_lse + r, R + 1));
+                                c->d_lse + r, R + 1, fold ? R : 0));
+                if (fold) c->run.logz_done = true;
                 ++launches;
             } else if (!fuse_scan || twist || r + 1 == R) {    // otherwise the next rank event's launch scans these weights
+                const bool fold = r + 1 == R && K <= PP_SCAN_KERNEL_MAX_KG;
                 CHK(launch_scan(c, (const double*)(c->d_logw + (size_t)r * K), K, 1, (r + 1 < R) ? c->d_cdf[nxt] : (uint64_t*)nullptr,
-                                c->d_lse + r, 0));
+                                c->d_lse + r, 0, fold ? R : 0));
+                if (fold) c->run.logz_done = true;
                 ++launches;
             }
         }
@@ -1225,12 +1243,14 @@ int phylo_sweep_finish(phylo_ctx* c) {
     const bool twist = c->run.twist, graph = c->run.graph, lazy = c->run.lazy, timek = c->run.timek;
     int launches = c->run.launches;
     (void)flags;
-    if (c->run.G > 1)
-        hipLaunchKernelGGL(pk_logz_total_groups, dim3(c->run.G), dim3(64), 0, c->stream, c->d_lse, R, R + 1);
-    else
-        hipLaunchKernelGGL(pk_logz_total, dim3(1), dim3(64), 0, c->stream, (const double*)c->d_lse, R, c->d_lse + R);
-    CHK(launch_check(c, "pk_logz_total"));
-    ++launches;
+    if (!c->run.logz_done) {
+        if (c->run.G > 1)
+            hipLaunchKernelGGL(pk_logz_total_groups, dim3(c->run.G), dim3(64), 0, c->stream, c->d_lse, R, R + 1);
+        else
+            hipLaunchKernelGGL(pk_logz_total, dim3(1), dim3(64), 0, c->stream, (const double*)c->d_lse, R, c->d_lse + R);
+        CHK(launch_check(c, "pk_logz_total"));
+        ++launches;
+    }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->swept = true;
     c->run.active = false;

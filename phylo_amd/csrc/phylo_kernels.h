@@ -98,12 +98,11 @@ __global__ __launch_bounds__(64) void pk_expm_batched(const double* __restrict__
 
 // all branch lengths and transition matrices of one sweep: thread per (rank event r, local particle k,
 // side).  b = -log(U)/lambda_r (vcsmc.py:351-356); Pmat[r][k] = {P(b_l), P(b_r)}.
-__global__ __launch_bounds__(64) void pk_sweep_draws(const double* __restrict__ Q, const double* __restrict__ lam_l,
-                                                     const double* __restrict__ lam_r, int jc, uint64_t seed, int R, int K,
-                                                     int k0, double* __restrict__ bl, double* __restrict__ br,
-                                                     double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds,
-                                                     unsigned long long* __restrict__ rdraw /*[R][K] or NULL: resampling draws*/) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pk_sweep_draws_body(int t, const double* __restrict__ Q, const double* __restrict__ lam_l,
+                                                    const double* __restrict__ lam_r, int jc, uint64_t seed, int R, int K,
+                                                    int k0, double* __restrict__ bl, double* __restrict__ br,
+                                                    double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds,
+                                                    unsigned long long* __restrict__ rdraw /*[R][K] or NULL: resampling draws*/) {
     if (t >= 2 * R * K) return;
     const int side = t & 1, i = t >> 1;
     const int r = i / K, k = i - r * K;
@@ -123,6 +122,52 @@ __global__ __launch_bounds__(64) void pk_sweep_draws(const double* __restrict__ 
     double* out = Pmat + (size_t)i * 32 + side * 16;
 #pragma unroll
     for (int j = 0; j < 16; ++j) out[j] = p[j];
+}
+__global__ __launch_bounds__(64) void pk_sweep_draws(const double* __restrict__ Q, const double* __restrict__ lam_l,
+                                                     const double* __restrict__ lam_r, int jc, uint64_t seed, int R, int K,
+                                                     int k0, double* __restrict__ bl, double* __restrict__ br,
+                                                     double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds,
+                                                     unsigned long long* __restrict__ rdraw) {
+    pk_sweep_draws_body(blockIdx.x * blockDim.x + threadIdx.x, Q, lam_l, lam_r, jc, seed, R, K, k0, bl, br, Pmat, Kg, group_seeds, rdraw);
+}
+
+// The prologue of a sweep of the plain proposal as ONE launch: the draws above, the initial root tables (pk_init_tables) and the
+// cleared marks of the lazy nodes (was a hipMemsetAsync, i.e. a fill kernel) are independent of one another.
+struct pk_prologue_args {
+    const double *Q, *lam_l, *lam_r;
+    int jc, R, Kloc, k0, Kg;
+    uint64_t seed;
+    double *bl, *br, *Pmat;
+    const uint64_t* group_seeds;
+    unsigned long long* rdraw;
+    int32_t *roots, *cnt;
+    double* rootll;
+    const double* nodell;
+    int K, N;
+    unsigned int* mark;                 // NULL: no marks to clear
+    unsigned int mark_words;            // multiple of 4
+    int draw_blocks, init_blocks;       // then the blocks that clear the marks
+};
+__global__ __launch_bounds__(64) void pk_sweep_prologue(const pk_prologue_args p) {
+    const int b = blockIdx.x;
+    if (b < p.draw_blocks) {
+        pk_sweep_draws_body(b * 64 + (int)threadIdx.x, p.Q, p.lam_l, p.lam_r, p.jc, p.seed, p.R, p.Kloc, p.k0, p.bl, p.br, p.Pmat, p.Kg,
+                            p.group_seeds, p.rdraw);
+    } else if (b < p.draw_blocks + p.init_blocks) {
+        const int i0 = ((b - p.draw_blocks) * 64 + (int)threadIdx.x) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i < p.K * p.N) {
+                p.roots[i] = i % p.N;
+                p.cnt[i] = 1;
+                p.rootll[i] = p.nodell[i % p.N];
+            }
+        }
+    } else {
+        const unsigned int w = (unsigned int)((b - p.draw_blocks - p.init_blocks) * 64 + (int)threadIdx.x) * 4u;
+        if (w < p.mark_words) *reinterpret_cast<uint4*>(p.mark + w) = make_uint4(0u, 0u, 0u, 0u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

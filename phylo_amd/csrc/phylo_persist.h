@@ -325,13 +325,22 @@ __device__ __forceinline__ void pp_scan(const double* logw, int Kg, unsigned lon
 
 // The same scan as a launch of its own (launches-per-rank-event path, phylo_resample, phylo_log_zsmc): one workgroup of 512
 // threads per group, cdf built in LDS and copied out.  Replaces pk_resample_scan(_groups) whenever the group fits LDS.
+// logz_R > 0: lse_out is element logz_R - 1 of a row of logz_R log-normalisers; their left-to-right sum (compute_log_ZSMC,
+// vcsmc.py:276) goes to element logz_R of the row -- the last scan of a sweep then needs no pk_logz_total launch behind it.
 template <int NT>
-__global__ __launch_bounds__(NT) void pp_resample_scan(const double* logw, int Kg, uint64_t* __restrict__ cdf, double* lse_out, int lse_stride) {
+__global__ __launch_bounds__(NT) void pp_resample_scan(const double* logw, int Kg, uint64_t* __restrict__ cdf, double* lse_out, int lse_stride,
+                                                       int logz_R) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     pp_scan_lds* sh = reinterpret_cast<pp_scan_lds*>(smem);
     unsigned long long* lcdf = reinterpret_cast<unsigned long long*>(smem + ((sizeof(pp_scan_lds) + 15) & ~(size_t)15));
     const int g = blockIdx.x;
     pp_scan<NT>(logw + (size_t)g * Kg, Kg, lcdf, lse_out ? lse_out + (size_t)g * lse_stride : (double*)nullptr, sh, cdf != nullptr);
+    if (logz_R > 0 && lse_out && threadIdx.x == 0) {       // thread 0 wrote the last element itself, the others come from earlier launches
+        double* row = lse_out + (size_t)g * lse_stride - (logz_R - 1);
+        double z = 0.0;
+        for (int r = 0; r < logz_R; ++r) z = z + row[r];
+        row[logz_R] = z;
+    }
     if (!cdf) return;
     __syncthreads();
     unsigned long long* out = reinterpret_cast<unsigned long long*>(cdf) + (size_t)g * Kg;
