@@ -34,6 +34,7 @@ struct sweep_run {                       // a sweep being issued rank event by r
     uint32_t flags = 0;
     int M = 1, launches = 0, next_r = 0;
     bool twist = false, graph = false, lazy = false, timek = false, fuse_scan = false, active = false, local_book = false;
+    bool mat_by_draws = false;             // sharded: owners find their adopted nodes from the draws (no pk_all_marks)
     bool logz_done = false;                // the last scan summed the log-normalisers (no pk_logz_total launch)
     bool book_mat = false;                 // bookkeeping and the writes of the adopted nodes share one launch (pk_rank_book_mat)
     int G = 1;                             // independent sweeps batched in this context (phylo_sweep_batch_async)
@@ -795,10 +796,16 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     // one sweep alone on one GPU with lazy nodes: the adopted nodes are written in the bookkeeping launch (pk_rank_book_mat), found
     // by the resampling draws, which pk_sweep_draws then leaves in d_rdraw.  Batched sweeps keep the separate launch (measured:
-    // 2.45e11 against 2.64e11 units/s with the grouped form of the combined launch).
+    // 2.62e11 against 2.64e11 units/s with the grouped form of the combined launch: nothing to gain).
     const bool book_mat = lazy && c->world == 1 && c->comm.transport == 0 && !fuse_scan && N <= 32 && S <= 4096 && G == 1 && Kl <= 8192 &&
                           !c->env.separate_materialise && !c->env.book_one_per_wave;
-    if (book_mat && !c->d_rdraw) CHK(dalloc(c, &c->d_rdraw, (size_t)R * K));
+    // sharded with lazy nodes: each owner finds ITS adopted nodes the same way (O(Kloc Kg / 64) comparisons) instead of every rank
+    // searching the ancestors of all K particles (pk_all_marks, O(K) on every rank whatever the number of GPUs)
+    const bool shard_form = c->world > 1 || (c->comm.transport != 0 && c->env.rehearse_sharded);
+    const bool mat_by_draws = lazy && shard_form && !twist && !c->env.replicated_book && !c->env.separate_materialise && S <= 4096 &&
+                              (((K / G) <= 4096 && Kl <= 8192) || ((K / G) % PK_MAT_GROUP == 0 && Kl % PK_MAT_GROUP == 0));
+    const bool want_rdraw = book_mat || mat_by_draws;
+    if (want_rdraw && !c->d_rdraw) CHK(dalloc(c, &c->d_rdraw, (size_t)R * K));
     const size_t mark_words = ((size_t)R * K + R + 3) & ~(size_t)3;
     int32_t* t_roots = graph ? c->d_hroots : c->d_roots[0];
     int32_t* t_cnt = graph ? c->d_hcnt : c->d_cnt[0];
@@ -809,14 +816,15 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
         pa.Q = c->d_Q; pa.lam_l = c->d_lam_l; pa.lam_r = c->d_lam_r; pa.jc = c->jc; pa.seed = seed; pa.R = R; pa.Kloc = Kl; pa.k0 = c->k0;
         pa.bl = c->d_bl; pa.br = c->d_br; pa.Pmat = c->d_Pmat; pa.Kg = K / G;
         pa.group_seeds = G > 1 ? (const uint64_t*)c->d_group_seeds : (const uint64_t*)nullptr;
-        pa.rdraw = book_mat ? c->d_rdraw : (unsigned long long*)nullptr;
+        pa.rdraw = want_rdraw ? c->d_rdraw : (unsigned long long*)nullptr;
         pa.roots = t_roots; pa.cnt = t_cnt; pa.rootll = t_rootll; pa.nodell = c->d_nodell; pa.K = K; pa.N = N;
         pa.mark = lazy ? c->d_mark : (unsigned int*)nullptr;
         pa.mark_words = lazy ? (unsigned int)mark_words : 0u;
         pa.draw_blocks = cdiv(2L * R * Kl, 64);
         pa.init_blocks = cdiv((long)K * N, 256);
-        const int mark_blocks = lazy ? cdiv((long)mark_words, 256) : 0;
-        hipLaunchKernelGGL(pk_sweep_prologue, dim3(pa.draw_blocks + pa.init_blocks + mark_blocks), dim3(64), 0, c->stream, pa);
+        pa.mark_blocks = lazy ? cdiv((long)mark_words, 256) : 0;
+        const int rdraw_blocks = want_rdraw ? cdiv((long)(R - 1) * K, 64) : 0;
+        hipLaunchKernelGGL(pk_sweep_prologue, dim3(pa.draw_blocks + pa.init_blocks + pa.mark_blocks + rdraw_blocks), dim3(64), 0, c->stream, pa);
         CHK(launch_check(c, "pk_sweep_prologue"));
         launches += 1;
     } else {
@@ -830,6 +838,7 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     c->run.seed = seed; c->run.flags = flags; c->run.M = M;
     c->run.twist = twist; c->run.graph = graph; c->run.lazy = lazy; c->run.timek = timek; c->run.fuse_scan = fuse_scan;
     c->run.book_mat = book_mat;
+    c->run.mat_by_draws = mat_by_draws;
     c->run.launches = launches; c->run.next_r = 0; c->run.active = true;
     c->run.G = G;
     return PHYLO_OK;
@@ -980,15 +989,23 @@ static int sweep_step_a(phylo_ctx* c) {
     b.leaves = c->d_leaves; b.pool = c->d_pool; b.pool_ptrs = c->d_pool_ptrs;
     b.leaf_codes = c->leaves_coded ? c->d_leaf_codes : nullptr;
     b.lazy = 1; b.mark = c->d_mark; b.child_all = c->d_child; b.Pmat_all = c->d_Pmat;
-    hipLaunchKernelGGL(pk_all_marks, dim3(cdiv(K, 4)), dim3(64), 0, c->stream, b);
-    CHK(launch_check(c, "pk_all_marks"));
-    // large launches of small nodes (batched sweeps): dispatching one workgroup per particle costs more than the few writes
-            if (S <= 4096 && Kl > 8192) hipLaunchKernelGGL(pk_materialize_adopted_grouped, dim3(cdiv(Kl, PK_MAT_GROUP)), dim3(PK_COLS), 0, c->stream, b);
-            else hipLaunchKernelGGL(pk_materialize_adopted, dim3(S <= 4096 ? 1 : cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
-    CHK(launch_check(c, "pk_materialize_adopted"));
+    if (c->run.mat_by_draws) {
+        b.rdraw = c->d_rdraw + (size_t)r * K;
+        const int grouped = ((K / G) > 4096 || Kl > 8192) ? 1 : 0;     // one workgroup per 64 particles when there are many
+        hipLaunchKernelGGL(pk_materialize_by_draws, dim3(grouped ? Kl / PK_MAT_GROUP : Kl), dim3(PK_COLS), 0, c->stream, b, grouped);
+        CHK(launch_check(c, "pk_materialize_by_draws"));
+        c->run.launches += 1;
+    } else {
+        hipLaunchKernelGGL(pk_all_marks, dim3(cdiv(K, 4)), dim3(64), 0, c->stream, b);
+        CHK(launch_check(c, "pk_all_marks"));
+        // large launches of small nodes (batched sweeps): dispatching one workgroup per particle costs more than the few writes
+        if (S <= 4096 && Kl > 8192) hipLaunchKernelGGL(pk_materialize_adopted_grouped, dim3(cdiv(Kl, PK_MAT_GROUP)), dim3(PK_COLS), 0, c->stream, b);
+        else hipLaunchKernelGGL(pk_materialize_adopted, dim3(S <= 4096 ? 1 : cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
+        CHK(launch_check(c, "pk_materialize_adopted"));
+        c->run.launches += 2;
+    }
     double* rows[1] = {c->d_sync};
     CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
-    c->run.launches += 2;
     return PHYLO_OK;
 }
 

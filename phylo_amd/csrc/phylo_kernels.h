@@ -101,17 +101,12 @@ __global__ __launch_bounds__(64) void pk_expm_batched(const double* __restrict__
 __device__ __forceinline__ void pk_sweep_draws_body(int t, const double* __restrict__ Q, const double* __restrict__ lam_l,
                                                     const double* __restrict__ lam_r, int jc, uint64_t seed, int R, int K,
                                                     int k0, double* __restrict__ bl, double* __restrict__ br,
-                                                    double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds,
-                                                    unsigned long long* __restrict__ rdraw /*[R][K] or NULL: resampling draws*/) {
+                                                    double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds) {
     if (t >= 2 * R * K) return;
     const int side = t & 1, i = t >> 1;
     const int r = i / K, k = i - r * K;
     int kp = k0 + k;                                      // particle index of the RNG contract
     if (group_seeds) { const int g = kp / Kg; seed = group_seeds[g]; kp -= g * Kg; }
-    if (rdraw && side == 0 && r > 0) {                    // the 64-bit draw the index search of rank event r scales by the cdf total
-        const pm_u32x4 d = pm_philox4x32((uint32_t)kp, (uint32_t)r, PM_STREAM_RESAMPLE, 0u, seed);
-        rdraw[i] = ((unsigned long long)d.y << 32) | d.x;
-    }
     const pm_u32x4 x = pm_philox4x32((uint32_t)kp, (uint32_t)r, PM_STREAM_BRANCH, 0u, seed);
     const double b = side ? (-pm_log(pm_unit_oc(x.z, x.w))) / lam_r[r] : (-pm_log(pm_unit_oc(x.x, x.y))) / lam_l[r];
     (side ? br : bl)[i] = b;
@@ -126,9 +121,8 @@ __device__ __forceinline__ void pk_sweep_draws_body(int t, const double* __restr
 __global__ __launch_bounds__(64) void pk_sweep_draws(const double* __restrict__ Q, const double* __restrict__ lam_l,
                                                      const double* __restrict__ lam_r, int jc, uint64_t seed, int R, int K,
                                                      int k0, double* __restrict__ bl, double* __restrict__ br,
-                                                     double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds,
-                                                     unsigned long long* __restrict__ rdraw) {
-    pk_sweep_draws_body(blockIdx.x * blockDim.x + threadIdx.x, Q, lam_l, lam_r, jc, seed, R, K, k0, bl, br, Pmat, Kg, group_seeds, rdraw);
+                                                     double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds) {
+    pk_sweep_draws_body(blockIdx.x * blockDim.x + threadIdx.x, Q, lam_l, lam_r, jc, seed, R, K, k0, bl, br, Pmat, Kg, group_seeds);
 }
 
 // The prologue of a sweep of the plain proposal as ONE launch: the draws above, the initial root tables (pk_init_tables) and the
@@ -139,20 +133,20 @@ struct pk_prologue_args {
     uint64_t seed;
     double *bl, *br, *Pmat;
     const uint64_t* group_seeds;
-    unsigned long long* rdraw;
+    unsigned long long* rdraw;          // [R][K] or NULL: the 64-bit resampling draw of every GLOBAL particle at every rank event
     int32_t *roots, *cnt;
     double* rootll;
     const double* nodell;
     int K, N;
     unsigned int* mark;                 // NULL: no marks to clear
     unsigned int mark_words;            // multiple of 4
-    int draw_blocks, init_blocks;       // then the blocks that clear the marks
+    int draw_blocks, init_blocks, mark_blocks;   // then the blocks that fill rdraw
 };
 __global__ __launch_bounds__(64) void pk_sweep_prologue(const pk_prologue_args p) {
     const int b = blockIdx.x;
     if (b < p.draw_blocks) {
         pk_sweep_draws_body(b * 64 + (int)threadIdx.x, p.Q, p.lam_l, p.lam_r, p.jc, p.seed, p.R, p.Kloc, p.k0, p.bl, p.br, p.Pmat, p.Kg,
-                            p.group_seeds, p.rdraw);
+                            p.group_seeds);
     } else if (b < p.draw_blocks + p.init_blocks) {
         const int i0 = ((b - p.draw_blocks) * 64 + (int)threadIdx.x) * 4;
 #pragma unroll
@@ -164,9 +158,19 @@ __global__ __launch_bounds__(64) void pk_sweep_prologue(const pk_prologue_args p
                 p.rootll[i] = p.nodell[i % p.N];
             }
         }
-    } else {
+    } else if (b < p.draw_blocks + p.init_blocks + p.mark_blocks) {
         const unsigned int w = (unsigned int)((b - p.draw_blocks - p.init_blocks) * 64 + (int)threadIdx.x) * 4u;
         if (w < p.mark_words) *reinterpret_cast<uint4*>(p.mark + w) = make_uint4(0u, 0u, 0u, 0u);
+    } else {                                              // the draw the index search of rank event r >= 1 scales by the cdf total
+        const long i = (long)(b - p.draw_blocks - p.init_blocks - p.mark_blocks) * 64 + (int)threadIdx.x + p.K;   // rows 1 .. R-1
+        if (i < (long)p.R * p.K) {
+            const int r = (int)(i / p.K);
+            int kp = (int)(i - (long)r * p.K);
+            uint64_t seed = p.seed;
+            if (p.group_seeds) { const int g = kp / p.Kg; seed = p.group_seeds[g]; kp -= g * p.Kg; }
+            const pm_u32x4 d = pm_philox4x32((uint32_t)kp, (uint32_t)r, PM_STREAM_RESAMPLE, 0u, seed);
+            p.rdraw[i] = ((unsigned long long)d.y << 32) | d.x;
+        }
     }
 }
 
@@ -1070,6 +1074,7 @@ __device__ __forceinline__ void pk_mat_by_thresholds(const pk_rank_args& a, int 
     }
     if (!__syncthreads_or((int)hit)) return;
     pk_materialize_node(a, a.r - 1, kg, tid, PK_COLS, 0, a.S);
+    if (tid == 0) a.mark[(size_t)(a.r - 1) * a.K + kg] = 1u;
 }
 __device__ __forceinline__ void pk_mat_by_thresholds_grouped(const pk_rank_args& a, int k0) {   // particles k0 .. k0 + 63, one group
     __shared__ unsigned long long gcdf[PK_MAT_GROUP];
@@ -1082,14 +1087,26 @@ __device__ __forceinline__ void pk_mat_by_thresholds_grouped(const pk_rank_args&
     const unsigned long long lo = kin0 > 0 ? a.cdf[gbase + kin0 - 1] : 0ull, total = a.cdf[gbase + Kg - 1];
     __syncthreads();
     const unsigned long long hi = gcdf[cnt - 1];
-    #pragma unroll 4
+    // a heavy particle attracts most of the Kg draws, so hits are NOT rare: every thread collects its hits in a register mask
+    // (binary search of the 64 cdf values in LDS), the masks are OR-ed across the wave by a butterfly and across waves in LDS
+    unsigned long long mine = 0ull;
+    #pragma unroll 2
     for (int i = tid; i < Kg; i += PK_COLS) {
         const unsigned long long t = pm_mulhi64(a.rdraw[gbase + i], total);
-        if (t >= lo && t < hi) {                          // rare (64 of Kg draws on average): first j with gcdf[j] > t
-            int j = 0;
-            while (gcdf[j] <= t) ++j;
-            atomicOr(&maskw[j >> 5], 1u << (j & 31));     // integer LDS atomic: the result does not depend on the order
+        if (t >= lo && t < hi) {                          // first j with gcdf[j] > t
+            int l = 0, h = cnt - 1;
+            while (l < h) {
+                const int m = (l + h) >> 1;
+                if (gcdf[m] > t) h = m; else l = m + 1;
+            }
+            mine |= 1ull << l;
         }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mine |= __shfl_xor(mine, off, 64);
+    if ((tid & 63) == 0 && mine) {
+        if ((unsigned int)mine) atomicOr(&maskw[0], (unsigned int)mine);            // four waves, integer OR: any order, same result
+        if ((unsigned int)(mine >> 32)) atomicOr(&maskw[1], (unsigned int)(mine >> 32));
     }
     __syncthreads();
     unsigned long long todo = ((unsigned long long)maskw[1] << 32) | maskw[0];
@@ -1097,7 +1114,14 @@ __device__ __forceinline__ void pk_mat_by_thresholds_grouped(const pk_rank_args&
         const int j = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         pk_materialize_node(a, a.r - 1, k0 + j, tid, PK_COLS, 0, a.S);
+        if (tid == 0) a.mark[(size_t)(a.r - 1) * a.K + k0 + j] = 1u;
     }
+}
+// the same as a launch of its own (sharded sweeps: each rank writes ITS adopted nodes before the barrier collective of the first
+// half of a rank event); grid: local particles, or groups of 64 of them
+__global__ __launch_bounds__(PK_COLS) void pk_materialize_by_draws(const pk_rank_args a, int grouped) {
+    if (grouped) pk_mat_by_thresholds_grouped(a, a.k0 + (int)blockIdx.x * PK_MAT_GROUP);
+    else pk_mat_by_thresholds(a, a.k0 + (int)blockIdx.x);
 }
 
 template <int LP>

@@ -178,13 +178,15 @@ def test_batched_sweeps_on_sharded_contexts(world, G, Kg):
         assert list(p['logz']) == [ref['logZ'] for ref in refs]                        # every rank holds every estimate
 
 
-@pytest.mark.parametrize("transport,world", [('hostshm', 2), ('rccl', 1)])
-def test_bench_loop_at_n_gt_1(transport, world):
+@pytest.mark.parametrize("transport,world,G,Kg", [('hostshm', 2, 3, 32), ('rccl', 1, 3, 32),
+                                                  ('hostshm', 2, 2, 8192), ('rccl', 1, 2, 8192)])
+def test_bench_loop_at_n_gt_1(transport, world, G, Kg):
     """bench.py's exact N > 1 loop: 2 ranks x 2 contexts on one shared communicator x 3 batched sweeps per context,
     phylo_sweep_batch_begin + phylo_sweep_step_a + phylo_sweep_step + phylo_sweep_finish, lazy nodes (the default): every one
     of the 6 sweeps equals the oracle's sweep of its seed.  Also with the real library on a one-rank world running the complete
-    sharded protocol."""
-    G, Kg, seed, inflight = 3, 32, 21, 2
+    sharded protocol.  Kg = 8192: the replicated scan of large groups, and the owners find their adopted nodes with one workgroup
+    per 64 particles (pk_materialize_by_draws, grouped form), as bench.py's launch sets of 20 480 particles per rank do."""
+    seed, inflight = 21, 2
     env = {'PHYLO_TEST_BATCH': str(G), 'PHYLO_TEST_INFLIGHT': str(inflight)}
     if transport == 'rccl':
         env.update(PHYLO_COMM_FORCE_RCCL='1', PHYLO_REHEARSE_SHARDED='1')
