@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -145,7 +146,13 @@ struct phylo_ctx {
     int last_G = 1;
     bool last_final_missing = false;
     std::vector<uint64_t> h_group_seeds;
-    std::vector<int32_t> h_csr;          // packed integer lists of the reverse pass (kept alive for the async copy)
+    // host copies of the kept graph's integer records, in pinned memory: copied asynchronously when the sweep ends, so that the
+    // reverse pass finds them on the host without a synchronous copy; and the pinned staging area of its packed integer lists
+    int64_t* h_anc_p = nullptr;          // [(R-1)][K]
+    int32_t *h_child_p = nullptr, *h_rad_p = nullptr, *h_csr_p = nullptr;   // [R][K][2], [R][K][N] (twisted), the d_ad_off slab
+    size_t h_csr_cap = 0;                // int32 elements
+    hipEvent_t ev_gcopy = nullptr;
+    std::vector<int32_t> h_cur;          // scratch of the counting sorts
     std::vector<int32_t> h_xlists;       // ... of its twisted part
     hipEvent_t evb0 = nullptr, evb1 = nullptr;
     phylo_stats stats{};
@@ -249,6 +256,14 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_leafpi = c->d_leafterm = c->d_terms = c->d_gout = nullptr;
     c->d_ad_off = c->d_ad_idx = c->d_par_off = c->d_par_idx = nullptr;
     c->d_heavy = c->d_chunk_beg = c->d_chunk_cnt = nullptr;
+    if (c->h_csr_p) (void)hipHostFree(c->h_csr_p);
+    if (c->h_anc_p) (void)hipHostFree(c->h_anc_p);
+    if (c->h_child_p) (void)hipHostFree(c->h_child_p);
+    if (c->h_rad_p) (void)hipHostFree(c->h_rad_p);
+    c->h_csr_p = c->h_child_p = c->h_rad_p = nullptr;
+    c->h_anc_p = nullptr;
+    if (c->ev_gcopy) (void)hipEventDestroy(c->ev_gcopy);
+    c->ev_gcopy = nullptr;
     c->graph_ready = false;
     c->last_graph = false;
     if (c->d_stamps) (void)hipFree(c->d_stamps);
@@ -347,7 +362,12 @@ int ensure_graph_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_gout, 2 * R + 20));
     {   // the integer lists of the reverse pass live in ONE slab, uploaded with one copy per step
         const size_t cap = 2 * R * K / 4 + 1;
-        CHK(dalloc(c, &c->d_ad_off, R * (K + 1) + R * K + (R * K + 1) + 2 * R * K + R * K + 2 * cap));
+        c->h_csr_cap = R * (K + 1) + R * K + (R * K + 1) + 2 * R * K + R * K + 2 * cap;
+        CHK(dalloc(c, &c->d_ad_off, c->h_csr_cap));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_csr_p, c->h_csr_cap * 4));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_anc_p, (R > 1 ? (R - 1) * K : 1) * 8));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_child_p, R * K * 2 * 4));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_gcopy, hipEventDisableTiming));
         c->d_ad_idx = c->d_ad_off + R * (K + 1);
         c->d_par_off = c->d_ad_idx + R * K;
         c->d_par_idx = c->d_par_off + R * K + 1;
@@ -780,6 +800,7 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
                 CHK(dalloc(c, &c->d_ctw, (size_t)R * K * N));
                 CHK(dalloc(c, &c->d_twnode, (size_t)R * K * PG_NODEG));
                 CHK(dalloc(c, &c->d_joff, (size_t)R + 1));
+                HIPCHK(c, hipHostMalloc((void**)&c->h_rad_p, (size_t)R * K * N * 4));
             }
             HIPCHK(c, hipMemcpyAsync(c->d_joff, c->h_joff.data(), ((size_t)R + 1) * 8, hipMemcpyHostToDevice, c->stream));
         }
@@ -1269,6 +1290,12 @@ int phylo_sweep_finish(phylo_ctx* c) {
         ++launches;
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    if (graph) {                                           // the reverse pass builds its lists from these on the host
+        if (R > 1) HIPCHK(c, hipMemcpyAsync(c->h_anc_p, c->d_anc, (size_t)(R - 1) * c->K * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_child_p, c->d_child, (size_t)R * c->K * 2 * 4, hipMemcpyDeviceToHost, c->stream));
+        if (twist) HIPCHK(c, hipMemcpyAsync(c->h_rad_p, c->d_hroots_ad, (size_t)R * c->K * N * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_gcopy, c->stream));
+    }
     c->swept = true;
     c->run.active = false;
     c->last_lazy = lazy;
@@ -1426,77 +1453,119 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         return fail(c, PHYLO_ESTATE, "phylo_sweep_backward needs a preceding sweep with PHYLO_KEEP_GRAPH");
     const int N = c->N, K = c->K, S = c->S, R = N - 1;
     const int T = (S + PG_NT - 1) / PG_NT;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    // integer bookkeeping of the reverse pass: who adopted whom, and which nodes have which parents
-    std::vector<int64_t> anc((size_t)(R > 1 ? R - 1 : 0) * K);
-    std::vector<int32_t> child((size_t)R * K * 2);
-    if (R > 1) HIPCHK(c, hipMemcpy(anc.data(), c->d_anc, anc.size() * 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(child.data(), c->d_child, child.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<int32_t> ad_off((size_t)R * (K + 1), 0), ad_idx((size_t)R * K, 0);
+    const bool twist = c->last_graph_twist;
+    const size_t nn = (size_t)R * K;
+    // ---- what does not need the integer lists is launched first: the GPU works while the host builds them
+    pg_args g{};
+    g.N = N; g.S = S; g.K = K; g.R = R; g.T = T; g.jc = c->jc;
+    g.twist = twist ? 1 : 0;
+    g.leaves = c->d_leaves; g.pool = c->d_pool; g.adj = c->d_adj; g.Pmat = c->d_Pmat;
+    g.bl = c->d_bl; g.br = c->d_br; g.logw = c->d_logw; g.lse = c->d_lse;
+    g.pi = c->d_pi; g.Q = c->d_Q; g.lam_l = c->d_lam_l; g.lam_r = c->d_lam_r;
+    g.child = c->d_child; g.pos = c->d_pos; g.roots = c->d_hroots;
+    g.ad_off = c->d_ad_off; g.ad_idx = c->d_ad_idx; g.par_off = c->d_par_off; g.par_idx = c->d_par_idx;
+    g.heavy_first = c->d_heavy; g.chunk_beg = c->d_chunk_beg; g.chunk_cnt = c->d_chunk_cnt;
+    g.om = c->d_om; g.G = c->d_G; g.C = c->d_C; g.part = c->d_part; g.nodeg = c->d_nodeg;
+    g.leafpi = c->d_leafpi; g.leafterm = c->d_leafterm; g.terms = c->d_terms; g.out = c->d_gout;
+    if (twist) {
+        g.tw.M = c->last_M; g.tw.joff = c->d_joff; g.tw.roots_ad = c->d_hroots_ad;
+        g.tw.tw_b = c->d_htw_b; g.tw.tw_P = c->d_htw_P; g.tw.pot = c->d_hpot; g.tw.chosen = c->d_hchosen;
+        g.tw.tau = c->d_tau; g.tw.ctw = c->d_ctw; g.tw.twpart = c->d_twpart; g.tw.twnode = c->d_twnode;
+        g.tw.pair_hist = (c->codes_valid && c->hist_ready) ? c->d_pair_hist : nullptr;
+    }
+    HIPCHK(c, hipEventRecord(c->evb0, c->stream));
+    const int nrk = cdiv((long)R * K, 256);
+    hipLaunchKernelGGL(pg_omega, dim3(nrk), dim3(256), 0, c->stream, g);
+    CHK(launch_check(c, "pg_omega"));
+    hipLaunchKernelGGL(pg_leafpi, dim3(N), dim3(256), 0, c->stream, g);
+    CHK(launch_check(c, "pg_leafpi"));
+    int tw_launches = 0;
+    if (twist) {
+        const size_t J0 = (size_t)((N * (N - 1)) / 2) * c->last_M;
+        hipLaunchKernelGGL(pg_twist_tau, dim3(R * K), dim3(64), J0 * 8, c->stream, g);
+        CHK(launch_check(c, "pg_twist_tau"));
+        hipLaunchKernelGGL(pg_twist_pbar, dim3((unsigned)((c->h_joff[R] + 3) / 4)), dim3(256), 0, c->stream, g);
+        CHK(launch_check(c, "pg_twist_pbar"));
+        if (g.tw.pair_hist)
+            for (int r = 0; r < R; ++r) {
+                const long rows_r = (long)(c->h_joff[r + 1] - c->h_joff[r]);
+                hipLaunchKernelGGL(pg_twist_pbar_ll, dim3(cdiv(rows_r, 64)), dim3(64), 0, c->stream, g, r);
+                CHK(launch_check(c, "pg_twist_pbar_ll"));
+                ++tw_launches;
+            }
+        for (int r = 0; r < R; ++r) {
+            const int Jr = (((N - r) * (N - r - 1)) / 2) * c->last_M;
+            const int KB = Jr >= 256 ? 1 : 256 / Jr;
+            hipLaunchKernelGGL(pg_twist_finish, dim3(cdiv(K, KB)), dim3(256), 0, c->stream, g, r);
+            CHK(launch_check(c, "pg_twist_finish"));
+            ++tw_launches;
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_adj, 0, (size_t)R * K * S * 4 * 8, c->stream));   // pg_twist_xsum accumulates, pg_nodes starts from it
+        tw_launches += 3;
+    }
+    // ---- integer bookkeeping of the reverse pass: who adopted whom, and which nodes have which parents.  The sweep left the
+    //      ancestors and children in pinned host memory (asynchronous copies behind its last launch); the lists are built straight
+    //      into the pinned image of the device slab (ad_off | ad_idx | par_off | par_idx | heavy | chunk_beg | chunk_cnt).
+    HIPCHK(c, hipEventSynchronize(c->ev_gcopy));
+    const int64_t* anc = c->h_anc_p;
+    const int32_t* child = c->h_child_p;
+    const size_t cap = 2 * nn / 4 + 1;
+    int32_t* ad_off = c->h_csr_p;
+    int32_t* ad_idx = ad_off + (size_t)R * (K + 1);
+    int32_t* par_off = ad_idx + nn;
+    int32_t* par_idx = par_off + nn + 1;
+    int32_t* heavy = par_idx + 2 * nn;
+    int32_t* chunk_beg = heavy + nn;
+    int32_t* chunk_cnt = chunk_beg + cap;
+    memset(ad_off, 0, ((size_t)R * (K + 1) + nn + nn + 1) * 4);      // ad_off, ad_idx, par_off
+    std::vector<int32_t>& cur = c->h_cur;
     for (int r = 1; r < R; ++r) {                          // counting sort by ancestor; ties keep ascending k'
-        int32_t* off = ad_off.data() + (size_t)r * (K + 1);
-        const int64_t* a = anc.data() + (size_t)(r - 1) * K;
+        int32_t* off = ad_off + (size_t)r * (K + 1);
+        const int64_t* a = anc + (size_t)(r - 1) * K;
         for (int k = 0; k < K; ++k) ++off[a[k] + 1];
         for (int k = 0; k < K; ++k) off[k + 1] += off[k];
-        std::vector<int32_t> cur(off, off + K);
-        int32_t* idx = ad_idx.data() + (size_t)r * K;
+        cur.assign(off, off + K);
+        int32_t* idx = ad_idx + (size_t)r * K;
         for (int k = 0; k < K; ++k) idx[cur[a[k]]++] = k;
     }
-    const size_t nn = (size_t)R * K;
-    std::vector<int32_t> par_off(nn + 1, 0), par_idx(2 * nn, 0);
     for (size_t e = 0; e < 2 * nn; ++e)
         if (child[e] >= N) ++par_off[(size_t)(child[e] - N) + 1];
     for (size_t i = 0; i < nn; ++i) par_off[i + 1] += par_off[i];
-    {
-        std::vector<int32_t> cur(par_off.begin(), par_off.end() - 1);
-        for (size_t e = 0; e < 2 * nn; ++e)                // e = node * 2 + side, ascending
-            if (child[e] >= N) par_idx[cur[child[e] - N]++] = (int32_t)e;
-    }
+    cur.assign(par_off, par_off + nn);
+    for (size_t e = 0; e < 2 * nn; ++e)                    // e = node * 2 + side, ascending
+        if (child[e] >= N) par_idx[cur[child[e] - N]++] = (int32_t)e;
     // heavy nodes (more than PG_PCHUNK parents): parent list cut into chunks, numbered within the node's rank event
-    std::vector<int32_t> heavy(nn, -1), chunk_beg, chunk_cnt, rank_chunk0((size_t)R + 1, 0);
-    size_t max_chunks = 0;
+    std::vector<int32_t> rank_chunk0((size_t)R + 1, 0);
+    size_t max_chunks = 0, n_chunks = 0;
     for (int r = 0; r < R; ++r) {
-        rank_chunk0[r] = (int32_t)chunk_beg.size();
+        rank_chunk0[r] = (int32_t)n_chunks;
         for (int k = 0; k < K; ++k) {
             const size_t x = (size_t)r * K + k;
             const int np = par_off[x + 1] - par_off[x];
+            heavy[x] = -1;
             if (np <= PG_PCHUNK) continue;
-            heavy[x] = (int32_t)(chunk_beg.size() - rank_chunk0[r]);
+            heavy[x] = (int32_t)(n_chunks - rank_chunk0[r]);
             for (int b = par_off[x]; b < par_off[x + 1]; b += PG_HCHUNK) {
-                chunk_beg.push_back(b);
-                chunk_cnt.push_back(par_off[x + 1] - b < PG_HCHUNK ? par_off[x + 1] - b : PG_HCHUNK);
+                chunk_beg[n_chunks] = b;
+                chunk_cnt[n_chunks] = par_off[x + 1] - b < PG_HCHUNK ? par_off[x + 1] - b : PG_HCHUNK;
+                ++n_chunks;
             }
         }
-        if (chunk_beg.size() - rank_chunk0[r] > max_chunks) max_chunks = chunk_beg.size() - rank_chunk0[r];
+        if (n_chunks - rank_chunk0[r] > max_chunks) max_chunks = n_chunks - rank_chunk0[r];
     }
-    rank_chunk0[R] = (int32_t)chunk_beg.size();
+    rank_chunk0[R] = (int32_t)n_chunks;
     void* cpart = nullptr;
     CHK(scratch_get(c, 5, max_chunks * (size_t)S * 4 * 8, &cpart));
-    {   // one packed upload (layout of the slab: ad_off | ad_idx | par_off | par_idx | heavy | chunk_beg | chunk_cnt)
-        const size_t cap = 2 * nn / 4 + 1;
-        std::vector<int32_t>& pk = c->h_csr;
-        pk.resize(ad_off.size() + ad_idx.size() + par_off.size() + par_idx.size() + heavy.size() + cap + chunk_cnt.size());
-        int32_t* w = pk.data();
-        memcpy(w, ad_off.data(), ad_off.size() * 4); w += ad_off.size();
-        memcpy(w, ad_idx.data(), ad_idx.size() * 4); w += ad_idx.size();
-        memcpy(w, par_off.data(), par_off.size() * 4); w += par_off.size();
-        memcpy(w, par_idx.data(), par_idx.size() * 4); w += par_idx.size();
-        memcpy(w, heavy.data(), heavy.size() * 4); w += heavy.size();
-        if (!chunk_beg.empty()) memcpy(w, chunk_beg.data(), chunk_beg.size() * 4);
-        w += cap;
-        if (!chunk_cnt.empty()) memcpy(w, chunk_cnt.data(), chunk_cnt.size() * 4);
-        HIPCHK(c, hipMemcpyAsync(c->d_ad_off, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, c->stream));
-    }
+    g.cpart = (double*)cpart;
+    HIPCHK(c, hipMemcpyAsync(c->d_ad_off, c->h_csr_p, c->h_csr_cap * 4, hipMemcpyHostToDevice, c->stream));
     // twisted proposal: the look-ahead merges of rank event r touch every internal node among the adopted roots.  Entries
     // (adopter, slot) grouped by node (ascending adopter), cut into chunks of PG_XCH; lists for all rank events in one upload.
-    const bool twist = c->last_graph_twist;
     std::vector<int32_t> ev_chunk0((size_t)R + 1, 0), ev_node0((size_t)R + 1, 0);
     size_t tw_max_chunks = 0;
     void *d_xlists = nullptr, *d_tpart = nullptr;
     size_t n_xent = 0, n_xchunks = 0, n_xnodes = 0;
     if (twist) {
-        std::vector<int32_t> rad((size_t)R * K * N);
-        HIPCHK(c, hipMemcpy(rad.data(), c->d_hroots_ad, rad.size() * 4, hipMemcpyDeviceToHost));
+        const int32_t* rad = c->h_rad_p;                            // pinned copy made when the sweep ended
         std::vector<int32_t> xent, xc_node, xc_beg, xc_cnt, xn_id, xn_c0, xn_nc;
         std::vector<int32_t> cnt, first;
         for (int r = 0; r < R; ++r) {
@@ -1506,7 +1575,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
             const int n = N - r;
             const size_t nn_r = (size_t)r * K;                      // nodes that exist before rank event r
             cnt.assign(nn_r + 1, 0);
-            const int32_t* tab = rad.data() + (size_t)r * K * N;
+            const int32_t* tab = rad + (size_t)r * K * N;
             for (int k = 0; k < K; ++k)
                 for (int i = 0; i < n; ++i) {
                     const int x = tab[(size_t)k * N + i];
@@ -1548,13 +1617,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         HIPCHK(c, hipMemcpyAsync(d_xlists, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, c->stream));
         CHK(scratch_get(c, 7, tw_max_chunks * (size_t)S * 4 * 8, &d_tpart));
     }
-    pg_args g{};
-    g.N = N; g.S = S; g.K = K; g.R = R; g.T = T; g.jc = c->jc;
-    g.twist = twist ? 1 : 0;
     if (twist) {
-        g.tw.M = c->last_M; g.tw.joff = c->d_joff; g.tw.roots_ad = c->d_hroots_ad;
-        g.tw.tw_b = c->d_htw_b; g.tw.tw_P = c->d_htw_P; g.tw.pot = c->d_hpot; g.tw.chosen = c->d_hchosen;
-        g.tw.tau = c->d_tau; g.tw.ctw = c->d_ctw; g.tw.twpart = c->d_twpart; g.tw.twnode = c->d_twnode;
         const int32_t* xl = (const int32_t*)d_xlists;
         g.tw.xent = xl; xl += n_xent;
         g.tw.xchunk_node = xl; xl += n_xchunks;
@@ -1564,52 +1627,13 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         g.tw.xnode_chunk0 = xl; xl += n_xnodes;
         g.tw.xnode_nchunks = xl;
         g.tw.tpart = (double*)d_tpart;
-        g.tw.pair_hist = (c->codes_valid && c->hist_ready) ? c->d_pair_hist : nullptr;
     }
-    g.heavy_first = c->d_heavy; g.chunk_beg = c->d_chunk_beg; g.chunk_cnt = c->d_chunk_cnt; g.cpart = (double*)cpart;
-    g.leaves = c->d_leaves; g.pool = c->d_pool; g.adj = c->d_adj; g.Pmat = c->d_Pmat;
-    g.bl = c->d_bl; g.br = c->d_br; g.logw = c->d_logw; g.lse = c->d_lse;
-    g.pi = c->d_pi; g.Q = c->d_Q; g.lam_l = c->d_lam_l; g.lam_r = c->d_lam_r;
-    g.child = c->d_child; g.pos = c->d_pos; g.roots = c->d_hroots;
-    g.ad_off = c->d_ad_off; g.ad_idx = c->d_ad_idx; g.par_off = c->d_par_off; g.par_idx = c->d_par_idx;
-    g.om = c->d_om; g.G = c->d_G; g.C = c->d_C; g.part = c->d_part; g.nodeg = c->d_nodeg;
-    g.leafpi = c->d_leafpi; g.leafterm = c->d_leafterm; g.terms = c->d_terms; g.out = c->d_gout;
-    HIPCHK(c, hipEventRecord(c->evb0, c->stream));
-    const int nrk = cdiv((long)R * K, 256);
-    hipLaunchKernelGGL(pg_omega, dim3(nrk), dim3(256), 0, c->stream, g);
-    CHK(launch_check(c, "pg_omega"));
     hipLaunchKernelGGL(pg_G, dim3(R * K), dim3(64), 0, c->stream, g);
     CHK(launch_check(c, "pg_G"));
-    int tw_launches = 0;
-    if (twist) {
-        const size_t J0 = (size_t)((N * (N - 1)) / 2) * c->last_M;
-        hipLaunchKernelGGL(pg_twist_tau, dim3(R * K), dim3(64), J0 * 8, c->stream, g);
-        CHK(launch_check(c, "pg_twist_tau"));
-        hipLaunchKernelGGL(pg_twist_pbar, dim3((unsigned)((c->h_joff[R] + 3) / 4)), dim3(256), 0, c->stream, g);
-        CHK(launch_check(c, "pg_twist_pbar"));
-        if (g.tw.pair_hist)
-            for (int r = 0; r < R; ++r) {
-                const long rows_r = (long)(c->h_joff[r + 1] - c->h_joff[r]);
-                hipLaunchKernelGGL(pg_twist_pbar_ll, dim3(cdiv(rows_r, 64)), dim3(64), 0, c->stream, g, r);
-                CHK(launch_check(c, "pg_twist_pbar_ll"));
-                ++tw_launches;
-            }
-        for (int r = 0; r < R; ++r) {
-            const int Jr = (((N - r) * (N - r - 1)) / 2) * c->last_M;
-            const int KB = Jr >= 256 ? 1 : 256 / Jr;
-            hipLaunchKernelGGL(pg_twist_finish, dim3(cdiv(K, KB)), dim3(256), 0, c->stream, g, r);
-            CHK(launch_check(c, "pg_twist_finish"));
-            ++tw_launches;
-        }
-        HIPCHK(c, hipMemsetAsync(c->d_adj, 0, (size_t)R * K * S * 4 * 8, c->stream));   // pg_twist_xsum accumulates, pg_nodes starts from it
-        tw_launches += 3;
-    }
     for (int r = R - 1; r >= 0; --r) {
         hipLaunchKernelGGL(pg_coeff, dim3(K, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r);
         CHK(launch_check(c, "pg_coeff"));
     }
-    hipLaunchKernelGGL(pg_leafpi, dim3(N), dim3(256), 0, c->stream, g);
-    CHK(launch_check(c, "pg_leafpi"));
     hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_leafterm"));
     for (int r = R - 1; r >= 0; --r) {
