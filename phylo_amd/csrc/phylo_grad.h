@@ -20,6 +20,7 @@
 #define PG_PCHUNK 8                    // parents staged in LDS at a time; more parents than this = a heavy node
 #define PG_HCHUNK 32                   // parents per chunk of a heavy node
 #define PG_NT 256                      // sites per workgroup of pg_nodes (4 steps of 64 sites)
+#define PG_RED_STRIDE 68                // doubles per value row of the LDS reductions: the 48 reading lanes spread over all banks
 
 #define PG_XCH 16                       // (adopter, slot) entries per chunk of pg_twist_xchunks
 
@@ -286,22 +287,32 @@ __device__ __forceinline__ void pg_stage_parents(const pg_args& a, int c0, int n
     }
 }
 
-// xb (state j of one site) += contributions of the nc staged parents; soff = s * 4 + j
+// xb (state j of one site) += contributions of the nc staged parents; soff = s * 4 + j.  All 2 nc loads are issued before the
+// first is used (index clamped, so no branch surrounds a load): a loop with a load inside pays one memory latency per parent, and
+// that -- not bandwidth or arithmetic -- was what pg_parent_chunks and the heavy nodes of pg_nodes cost.
 __device__ __forceinline__ double pg_parent_quad(const pg_args& a, size_t soff, int j, int nc, const double (*shP)[32],
                                                  const int* shE, const int* shSib, double xb) {
     const size_t row = (size_t)a.S * 4;
-    for (int e = 0; e < nc; ++e) {
-        const int enc = shE[e];
-        const int pn = enc >> 1, side = enc & 1;
-        const double xp = a.adj[(size_t)pn * row + soff];
-        const double sb = pg_row(a, shSib[e])[soff];
-        const double* Psib = shP[e] + (1 - side) * 16;
-        const double* Pme = shP[e] + side * 16;
-        const double b0 = pg_quad<0>(sb), b1 = pg_quad<1>(sb), b2 = pg_quad<2>(sb), b3 = pg_quad<3>(sb);
-        const double w = pg_dot4(b0, Psib[j], b1, Psib[4 + j], b2, Psib[8 + j], b3, Psib[12 + j]);
-        const double t = xp * w;
-        const double t0 = pg_quad<0>(t), t1 = pg_quad<1>(t), t2 = pg_quad<2>(t), t3 = pg_quad<3>(t);
-        xb = xb + pg_dot4(t0, Pme[j * 4], t1, Pme[j * 4 + 1], t2, Pme[j * 4 + 2], t3, Pme[j * 4 + 3]);
+    double xpv[PG_PCHUNK], sbv[PG_PCHUNK];
+#pragma unroll
+    for (int e = 0; e < PG_PCHUNK; ++e) {
+        const int ee = e < nc ? e : nc - 1;
+        xpv[e] = a.adj[(size_t)(shE[ee] >> 1) * row + soff];
+        sbv[e] = pg_row(a, shSib[ee])[soff];
+    }
+#pragma unroll
+    for (int e = 0; e < PG_PCHUNK; ++e) {
+        if (e < nc) {                                        // workgroup-uniform
+            const int side = shE[e] & 1;
+            const double* Psib = shP[e] + (1 - side) * 16;
+            const double* Pme = shP[e] + side * 16;
+            const double sb = sbv[e];
+            const double b0 = pg_quad<0>(sb), b1 = pg_quad<1>(sb), b2 = pg_quad<2>(sb), b3 = pg_quad<3>(sb);
+            const double w = pg_dot4(b0, Psib[j], b1, Psib[4 + j], b2, Psib[8 + j], b3, Psib[12 + j]);
+            const double t = xpv[e] * w;
+            const double t0 = pg_quad<0>(t), t1 = pg_quad<1>(t), t2 = pg_quad<2>(t), t3 = pg_quad<3>(t);
+            xb = xb + pg_dot4(t0, Pme[j * 4], t1, Pme[j * 4 + 1], t2, Pme[j * 4 + 2], t3, Pme[j * 4 + 3]);
+        }
     }
     return xb;
 }
@@ -421,6 +432,143 @@ __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
         const int i = tid < 32 ? (tid >> 2) : 8, jj = tid & 3;
         a.part[(node * a.T + tile) * PG_PART + tid] = ((shR[0][i][jj] + shR[1][i][jj]) + shR[2][i][jj]) + shR[3][i][jj];
     }
+}
+
+// The same for small nodes (S <= 4096), row form: one workgroup per node, thread = site (sites tid, tid + 256, ...), the node's
+// own matrices in scalar registers, whole 32-byte rows per load, fused multiply-adds, and ONE reduction of the 36 sums per node
+// (through LDS) instead of one per 256-site tile.  The quad form above spends most of its instructions on DPP broadcasts and
+// on reducing 9 sums per lane for every tile; here a site costs about 80 instructions in all.  grid (K), part has one tile (T = 1).
+__global__ __launch_bounds__(256, 4) void pg_nodes_rows(pg_args a, int r) {
+    __shared__ double shP[PG_PCHUNK][32];
+    __shared__ int shE[PG_PCHUNK];
+    __shared__ int shSib[PG_PCHUNK];
+    __shared__ double red[4][12][PG_RED_STRIDE];
+    __shared__ double shW[4][PG_PART];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t node = (size_t)r * a.K + k;
+    const size_t row = (size_t)a.S * 4;
+    const double alpha = a.C[node * a.N + (a.N - r - 2)];
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    const int pbeg = a.par_off[node], pend = a.par_off[node + 1];
+    const int hv = a.heavy_first[node];
+    const int np = pend - pbeg;
+    const int nch = hv >= 0 ? (np + PG_HCHUNK - 1) / PG_HCHUNK : 0;
+    if (hv < 0 && np > 0) pg_stage_parents(a, pbeg, np, shP, shE, shSib);
+    const double* Pu = a.Pmat + node * 32;
+    double Pl[16], Pr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { Pl[i] = Pu[i]; Pr[i] = Pu[16 + i]; }
+    __syncthreads();
+    const double* Lrow = pg_row(a, a.child[node * 2]);
+    const double* Rrow = pg_row(a, a.child[node * 2 + 1]);
+    const double* xrow = a.pool + node * row;
+    double* orow = a.adj + node * row;
+    double acc[PG_PART];
+#pragma unroll
+    for (int i = 0; i < PG_PART; ++i) acc[i] = 0.0;
+    // phase A: the adjoint row (own term + parents), written to adj; phase B re-reads it (L2) for the matrix adjoints.  Two loops
+    // keep either phase below 128 registers (one loop: 207, two waves per SIMD).
+    #pragma unroll 1
+    for (int s = tid; s < a.S; s += 256) {
+        const size_t so = (size_t)s * 4;
+        double x[4], xb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = xrow[so + i];
+        const double lik = pg_dot4(pi[0], x[0], pi[1], x[1], pi[2], x[2], pi[3], x[3]);
+        const double inv = alpha / lik;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xb[j] = pi[j] * inv;
+            acc[32 + j] = __builtin_fma(x[j], inv, acc[32 + j]);
+        }
+        if (a.twist) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xb[j] = xb[j] + orow[so + j];
+        }
+        if (hv >= 0) {                                       // chunk sums, eight rows in flight (added in order)
+            const double* cp = a.cpart + (size_t)hv * row + so;
+            for (int c0 = 0; c0 < nch; c0 += 8) {
+                double q[8][4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int cc = c0 + u < nch ? c0 + u : nch - 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[u][j] = cp[(size_t)cc * row + j];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c0 + u < nch) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xb[j] = xb[j] + q[u][j];
+                    }
+            }
+        } else {
+            for (int e0 = 0; e0 < np; e0 += 4) {             // the light node's own parents, four at a time, loads first
+                double xp[4][4], sb[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ee = e0 + u < np ? e0 + u : np - 1;
+                    const double* xpp = a.adj + (size_t)(shE[ee] >> 1) * row + so;
+                    const double* sbp = pg_row(a, shSib[ee]) + so;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { xp[u][j] = xpp[j]; sb[u][j] = sbp[j]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (e0 + u < np) {
+                        const int e = e0 + u, side = shE[e] & 1;
+                        const double* Psib = shP[e] + (1 - side) * 16;
+                        const double* Pme = shP[e] + side * 16;
+                        double t[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            t[j] = xp[u][j] * pg_dot4(sb[u][0], Psib[j], sb[u][1], Psib[4 + j], sb[u][2], Psib[8 + j], sb[u][3], Psib[12 + j]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            xb[j] = xb[j] + pg_dot4(t[0], Pme[j * 4], t[1], Pme[j * 4 + 1], t[2], Pme[j * 4 + 2], t[3], Pme[j * 4 + 3]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) orow[so + j] = xb[j];
+    }
+    #pragma unroll 1
+    for (int s = tid; s < a.S; s += 256) {                   // (a thread re-reads only what it wrote itself)
+        const size_t so = (size_t)s * 4;
+        double L[4], Rv[4], xb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { L[i] = Lrow[so + i]; Rv[i] = Rrow[so + i]; xb[i] = orow[so + i]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double u = pg_dot4(L[0], Pl[j], L[1], Pl[4 + j], L[2], Pl[8 + j], L[3], Pl[12 + j]);
+            const double v = pg_dot4(Rv[0], Pr[j], Rv[1], Pr[4 + j], Rv[2], Pr[8 + j], Rv[3], Pr[12 + j]);
+            const double tl = xb[j] * v, tr = xb[j] * u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i * 4 + j] = __builtin_fma(L[i], tl, acc[i * 4 + j]);
+                acc[16 + i * 4 + j] = __builtin_fma(Rv[i], tr, acc[16 + i * 4 + j]);
+            }
+        }
+    }
+    const int q = lane >> 2, part = lane & 3;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {                            // per wave through its own LDS rows, then the four waves in order
+#pragma unroll
+        for (int i = 0; i < 12; ++i) red[wv][i][lane] = acc[b * 12 + i];
+        __builtin_amdgcn_wave_barrier();
+        double v = 0.0;
+        if (q < 12) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v = v + red[wv][q][part + 4 * i];
+        }
+        v = v + pg_quad_sum_step<1>(v);
+        v = v + pg_quad_sum_step<2>(v);
+        if (q < 12 && part == 0) shW[wv][b * 12 + q] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (tid < PG_PART) a.part[node * PG_PART + tid] = ((shW[0][tid] + shW[1][tid]) + shW[2][tid]) + shW[3][tid];
 }
 
 // ---- g6: per node: tiles -> Pl_bar, Pr_bar -> branch adjoints and the Q adjoint ----------------------------
@@ -621,7 +769,6 @@ __device__ __forceinline__ void pg_pbar_site(const double (&x1)[4], const double
 
 // one wave per row (4 rows per workgroup).  Rows of two coded leaves are left to pg_twist_pbar_ll.
 // The 36 sums over the wave's 64 lanes go through LDS, 12 at a time: lane (q, part) adds 16 of the 64 values of sum q.
-#define PG_RED_STRIDE 68               // doubles per value row: the 48 reading lanes spread over all banks
 __global__ __launch_bounds__(256) void pg_twist_pbar(pg_args a) {
     __shared__ double red[4][12][PG_RED_STRIDE];
     const int lane = threadIdx.x & 63;

@@ -1452,7 +1452,8 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     if (!c->swept || !c->last_graph)
         return fail(c, PHYLO_ESTATE, "phylo_sweep_backward needs a preceding sweep with PHYLO_KEEP_GRAPH");
     const int N = c->N, K = c->K, S = c->S, R = N - 1;
-    const int T = (S + PG_NT - 1) / PG_NT;
+    const bool rows_form = S <= 4096;                     // pg_nodes_rows: one workgroup per node, one tile
+    const int T = rows_form ? 1 : (S + PG_NT - 1) / PG_NT;
     const bool twist = c->last_graph_twist;
     const size_t nn = (size_t)R * K;
     // ---- what does not need the integer lists is launched first: the GPU works while the host builds them
@@ -1649,7 +1650,8 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
             hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 64), nch), dim3(256), 0, c->stream, g, (int)rank_chunk0[r]);
             CHK(launch_check(c, "pg_parent_chunks"));
         }
-        hipLaunchKernelGGL(pg_nodes, dim3(T, K), dim3(256), 0, c->stream, g, r);
+        if (rows_form) hipLaunchKernelGGL(pg_nodes_rows, dim3(K), dim3(256), 0, c->stream, g, r);
+        else hipLaunchKernelGGL(pg_nodes, dim3(T, K), dim3(256), 0, c->stream, g, r);
         CHK(launch_check(c, "pg_nodes"));
     }
     hipLaunchKernelGGL(pg_node_finish, dim3(cdiv((long)R * K, 64)), dim3(64), 0, c->stream, g);
