@@ -36,7 +36,8 @@ struct pg_twist {
     const double* chosen;              // [R][K] chosen sub-sample
     double* tau;                       // [rows] d logZ / d pot
     double* ctw;                       // [R][K][N] coefficient of sum_s log(pi . X) of every slot of the adopted table
-    double* twpart;                    // [rows][PG_PART] Pl_bar, Pr_bar, pi_bar of the row's merge, before the factor tau
+    double* twpart;                    // [PG_PART][rows] (value-major: pg_twist_finish reads a value of 256 consecutive rows with one
+                                       // coalesced load) Pl_bar, Pr_bar, pi_bar of the row's merge, before the factor tau
     double* twnode;                    // [R][K][PG_NODEG] per particle: d_lam_l, d_lam_r terms, Q_bar, pi_bar of its rows
     // adjoints of the adopted roots: entries (adopter * N + slot) grouped by node, cut into chunks of PG_XCH
     const int32_t* xent;
@@ -103,7 +104,7 @@ __device__ __forceinline__ const double* pg_row(const pg_args& a, int id) {
 
 // Frechet derivative of the matrix exponential, L(A, E) = d/dt exp(A + t E) at t = 0, by a scaled Taylor
 // series on the pair (X, dX) (the blocks of exp [[A, E], [0, A]]) and pairwise squaring.  ||A||_1 <= 1/2 after
-// scaling and 18 terms leave a truncation error below 1e-22.
+// scaling and up to 18 terms (chosen from the scaled norm) leave a truncation error below 1e-17.
 __device__ inline void pg_expm4_frechet(const double* A0, const double* E0, double* Lout) {
     double A[16], E[16], X[16], D[16], SX[16], SD[16], T1[16], T2[16];
     double norm = 0.0;
@@ -126,8 +127,12 @@ __device__ inline void pg_expm4_frechet(const double* A0, const double* E0, doub
         X[i] = id; D[i] = 0.0;                 // term 0
         SX[i] = id; SD[i] = 0.0;
     }
+    // terms for a truncation error below 1e-17 of the scaled pair (theta = norm after scaling <= 1/2): theta^n / n! with one term
+    // of margin for the derivative series.  Branch lengths are ~Exp(10), so most evaluations need 10, not 18
+    const double theta = norm * sc;
+    const int nterms = theta <= 0.01 ? 8 : theta <= 0.05 ? 10 : theta <= 0.15 ? 13 : theta <= 0.3 ? 15 : 18;
 #pragma unroll 1
-    for (int k = 1; k <= 18; ++k) {
+    for (int k = 1; k <= nterms; ++k) {
         const double inv = 1.0 / (double)k;
         pm_mm4(X, E, T1);                      // D_k = (X_{k-1} E + D_{k-1} A) / k
         pm_mm4(D, A, T2);
@@ -797,7 +802,8 @@ __global__ __launch_bounds__(256) void pg_twist_pbar(pg_args a) {
         for (int i = 0; i < 4; ++i) { x1[i] = X1[(size_t)s * 4 + i]; x2[i] = X2[(size_t)s * 4 + i]; }
         pg_pbar_site(x1, x2, Pl, Pr, pi, 1.0, acc);
     }
-    double* out = a.tw.twpart + (size_t)row * PG_PART;
+    double* out = a.tw.twpart + (size_t)row;
+    const size_t nrows = (size_t)a.tw.joff[a.R];
     const int q = lane >> 2, part = lane & 3;
 #pragma unroll
     for (int b = 0; b < 3; ++b) {                            // a wave's own LDS rows: no workgroup barrier needed
@@ -811,7 +817,7 @@ __global__ __launch_bounds__(256) void pg_twist_pbar(pg_args a) {
         }
         v = v + pg_quad_sum_step<1>(v);
         v = v + pg_quad_sum_step<2>(v);
-        if (q < 12 && part == 0) out[b * 12 + q] = v;
+        if (q < 12 && part == 0) out[(size_t)(b * 12 + q) * nrows] = v;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -851,9 +857,9 @@ __global__ __launch_bounds__(64) void pg_twist_pbar_ll(pg_args a, int r) {
         }
         pg_pbar_site(x1, x2, Pl, Pr, pi, (double)cnt, acc);
     }
-    double* out = a.tw.twpart + row * PG_PART;
+    const size_t nrows = (size_t)a.tw.joff[a.R];
 #pragma unroll
-    for (int i = 0; i < PG_PART; ++i) out[i] = acc[i];
+    for (int i = 0; i < PG_PART; ++i) a.tw.twpart[(size_t)i * nrows + row] = acc[i];
 }
 
 // Rows of rank event r -> branch adjoints -> rate terms, Frechet terms -> Q adjoint, summed per particle.  A workgroup takes
@@ -882,12 +888,13 @@ __global__ __launch_bounds__(256) void pg_twist_finish(pg_args a, int r) {
         const size_t row = row0 + t;
         const double tau = t < nrows ? a.tw.tau[row] : 0.0;
         if (tau != 0.0) {
-            const double* pp = a.tw.twpart + row * PG_PART;
+            const double* pp = a.tw.twpart + row;
+            const size_t nrows_all = (size_t)a.tw.joff[a.R];
 #pragma unroll 1
             for (int side = 0; side < 2; ++side) {
                 double Pm[16], QP[16], pb[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { Pm[i] = a.tw.tw_P[row * 32 + side * 16 + i]; pb[i] = tau * pp[side * 16 + i]; }
+                for (int i = 0; i < 16; ++i) { Pm[i] = a.tw.tw_P[row * 32 + side * 16 + i]; pb[i] = tau * pp[(size_t)(side * 16 + i) * nrows_all]; }
                 pm_mm4(Q, Pm, QP);
                 double bb = 0.0;
 #pragma unroll
@@ -906,7 +913,7 @@ __global__ __launch_bounds__(256) void pg_twist_finish(pg_args a, int r) {
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) res[18 + q] = tau * pp[32 + q];
+            for (int q = 0; q < 4; ++q) res[18 + q] = tau * pp[(size_t)(32 + q) * nrows_all];
         }
 #pragma unroll
         for (int i = 0; i < PG_NODEG; ++i) tot[i] = tot[i] + res[i];
