@@ -291,11 +291,27 @@ def main():
     # lazy nodes (plain proposal): the launch stores nothing and runs the row-per-thread form of the merge
     lazy_nodes = not a.twisting and not a.eager and not os.environ.get('PHYLO_EAGER_NODES')
     merge_kernel = "pk_rank_merge_nostore" if lazy_nodes else "pk_rank_merge"
+    if a.twisting:
+        # the dominant kernel of a twisted sweep is the look-ahead potentials (PHYLO_TIME_KERNELS stamps it): 64 B per look-ahead
+        # unit (two child reads, no store), K M S C(N+1,3) units per sweep, averaged over the N-1 launches of a sweep
+        merge_kernel = "pk_twist_potentials"
+        bytes_per_launch = 64.0 * ctx.K_local * a.M * S * ((N + 1) * N * (N - 1) / 6.0) / (N - 1)
     avg_s = merge_ms / merge_n * 1e-3
     alg_equiv = bytes_per_launch / avg_s / 1e9
     # counters of the committed rocprofv3 --pmc runs at THIS launch shape (they cannot be read inside the run)
     pmc = None
-    for tpath in sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', 'r*_merge_pmc.json')), reverse=True):
+    if a.twisting:
+        for tpath in sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', 'r*_twist_pmc.json')), reverse=True):
+            try:
+                for e in json.load(open(tpath)).get('kernels', []):
+                    if e.get('workload') == wname and e.get('kernel') == merge_kernel and e.get('M') == a.M and e.get('particles') == ctx.K_local:
+                        pmc = dict(e, source=os.path.basename(tpath))
+                        break
+            except Exception:
+                pass
+            if pmc:
+                break
+    for tpath in ([] if a.twisting else sorted(__import__('glob').glob(os.path.join(ROOT, 'profiles', 'r*_merge_pmc.json')), reverse=True)):
         try:
             for e in json.load(open(tpath)).get('launch_shapes', []):
                 if e.get('workload') == wname and e.get('particles_per_launch') == ctx.K_local and e.get('kernel') == merge_kernel:
@@ -312,7 +328,9 @@ def main():
         bound = "valu"
     roof = {"kernel": merge_kernel, "avg_launch_us": avg_s * 1e6, "particles_per_launch": ctx.K_local,
             "alg_bytes_per_launch": bytes_per_launch, "alg_equiv_GBps": alg_equiv,
-            "alg_equiv_note": "96 B x units / duration: an algorithmic-equivalent rate, not HBM traffic (lazy nodes store nothing; children are 1-byte codes or L2-resident)",
+            "alg_equiv_note": ("64 B x look-ahead units / duration, averaged over the rank events: an algorithmic-equivalent rate, not HBM traffic"
+                               if a.twisting else
+                               "96 B x units / duration: an algorithmic-equivalent rate, not HBM traffic (lazy nodes store nothing; children are 1-byte codes or L2-resident)"),
             "traffic": None, "hbm_frac": None, "valu_frac": None, "pmc_source": pmc['source'] if pmc else None}
     if pmc:
         if pmc.get('hbm_bytes_per_launch') is not None:

@@ -66,8 +66,9 @@ enum {
 
 typedef struct phylo_stats {
     double sweep_ms;        /* device time of the whole sweep (hipEvents on the ctx stream)            */
-    double merge_ms;        /* sum of merge-kernel launch durations (only with PHYLO_TIME_KERNELS)     */
-    int32_t merge_launches; /* number of merge launches in that sum                                    */
+    double merge_ms;        /* sum of the launch durations of the rank events' dominant kernel (only with PHYLO_TIME_KERNELS):
+                               the merge, or pk_twist_potentials for a twisted sweep                       */
+    int32_t merge_launches; /* number of launches in that sum                                          */
     int32_t n_launches;     /* kernel launches in the sweep                                            */
     double units;           /* particle-site-likelihoods computed by this rank: K_local * S * (N-1)    */
     double alg_bytes;       /* 96 B * units (two child reads + one parent write, fp64 x 4 states)      */

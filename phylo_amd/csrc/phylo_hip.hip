@@ -1109,7 +1109,11 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                 CHK(launch_check(c, "pk_twist_potentials_ll"));
                 ++launches;
             }
-            hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((((size_t)Kl * (N - r - 1) + 7) / 8) * 8)), dim3(PK_COLS), 0, c->stream, ta);
+            if (timek)     // a twisted sweep's dominant kernel is this one: PHYLO_TIME_KERNELS stamps it instead of the merge
+                hipExtLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((((size_t)Kl * (N - r - 1) + 7) / 8) * 8)), dim3(PK_COLS), 0, c->stream,
+                                      c->kev[2 * r], c->kev[2 * r + 1], 0, ta);
+            else
+                hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((((size_t)Kl * (N - r - 1) + 7) / 8) * 8)), dim3(PK_COLS), 0, c->stream, ta);
             CHK(launch_check(c, "pk_twist_potentials"));
             hipLaunchKernelGGL(pk_twist_choose, dim3(Kl), dim3(64), (size_t)ta.J * 8, c->stream, ta);
             CHK(launch_check(c, "pk_twist_choose"));
@@ -1180,7 +1184,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             }
         }
         const bool nostore = (b.lazy || b.no_store) && !c->env.merge_pair_form;   // row-per-thread form when nothing is stored
-        if (timek) {  // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
+        if (timek && !twist) {  // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
             if (nostore) hipExtLaunchKernelGGL(pk_rank_merge_nostore, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
             else hipExtLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
         } else if (nostore) {

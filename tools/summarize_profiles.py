@@ -149,5 +149,15 @@ if f:
             c['SQ_INSTS_SALU'], c['SQ_INSTS_LDS'], c['SQ_WAIT_ANY'] / max(c['SQ_WAVE_CYCLES'], 1),
             "%.3f" % (c['SQ_INSTS_VALU'] * 4.0 / (N_SIMD * CLK * us * 1e-6)) if us else "-"))
     lines.append("")
+    tw_out = []
+    for name in sorted(tw):
+        c = {k: sum(v) / len(v) for k, v in tw[name].items()}
+        us = sum(tdur[name]) / len(tdur[name]) if tdur.get(name) else None
+        tw_out.append({"workload": WORKLOAD, "kernel": name, "M": 1, "particles": 2048, "launches": len(tw[name]['SQ_WAVES']),
+                       "sq_insts_valu_per_launch": c.get('SQ_INSTS_VALU'), "sq_waves_per_launch": c.get('SQ_WAVES'),
+                       "sq_insts_salu_per_launch": c.get('SQ_INSTS_SALU'), "sq_insts_lds_per_launch": c.get('SQ_INSTS_LDS'),
+                       "avg_us_in_trace_pass": us, "note": "averages over the N-1 rank events of a sweep (their launch sizes differ)"})
+    json.dump({"round": tag, "command": "rocprofv3 --kernel-trace --pmc <SQ counters> -- python3 bench.py --twisting --M 1 --steps 3 --warmup 1 --streams 1 "
+               "--no-cpu-baseline --no-parity --min-timed-ms 0", "kernels": tw_out}, open(os.path.join(dst, "%s_twist_pmc.json" % tag), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
