@@ -73,10 +73,34 @@ def parse():
                                                   'instead of the untrained model')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true', help='skip the 10-seed comparison with the C oracle')
+    p.add_argument('--no-vi-step', action='store_true', help='skip the timing of the VI training steps (SURVEY 8f.1) appended to the line')
     p.add_argument('--min-timed-ms', type=float, default=100.0, help='repeat the K timed steps until this much time is covered')
     p.add_argument('--one-launch', action='store_true', help='single sweeps (t_sweep) in the one-launch form (phylo_persist.h)')
     p.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline duration')
     return p.parse_args()
+
+
+def vi_step_timing(g, K, device=0, steps=12):
+    """One VI training step of the widened path: sweep with the graph kept + hand-written reverse pass + Adam, all S
+    sites, plain and twisted (M = 1) proposal.  Device times from hipEvents, step time is wall clock; medians of `steps` steps."""
+    from phylo_amd import train as T
+    N, S, _ = g.shape
+    out = {"K": K, "sites": S, "optimizer": "Adam", "unit": "ms", "timer": "hipEvents (sweep, reverse pass); wall clock (step)"}
+    for name, nested in (("plain", False), ("twisted_M1", True)):
+        v = T.Variables(N, np.log(10.0), False)
+        tr = T.Trainer(g, K, v, T.make_optimizer('Adam', 0.01), S, device=device, nested=nested, M=1)
+        fw, bw, wall = [], [], []
+        try:
+            for i in range(steps + 3):
+                t0 = time.perf_counter()
+                tr.step(np.arange(S), seed=i)
+                t1 = time.perf_counter()
+                if i >= 3:
+                    fw.append(tr.last['raw']['forward_ms']); bw.append(tr.last['raw']['backward_ms']); wall.append((t1 - t0) * 1e3)
+        finally:
+            tr.close()
+        out[name] = {"sweep_ms": float(np.median(fw)), "reverse_ms": float(np.median(bw)), "step_wall_ms": float(np.median(wall))}
+    return out
 
 
 def cpu_baseline(g, Q, pi, lam, jc, K_gpu, seconds, twist_M=0, lam_r=None):
@@ -374,6 +398,8 @@ def main():
         }
         if parity is not None:
             line.update(parity)
+        if world == 1 and not a.no_vi_step and not a.synthetic:
+            line["vi_step"] = vi_step_timing(g, a.n_particles, device=local_rank % ndev)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds, a.M if a.twisting else 0, lam_r)
         print(json.dumps(line), flush=True)

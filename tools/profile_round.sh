@@ -12,7 +12,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$REPO/bench.py"
-COMMON="--no-cpu-baseline --no-parity --min-timed-ms 0"
+COMMON="--no-cpu-baseline --no-parity --no-vi-step --min-timed-ms 0"
 run() { local rn=$1; shift; echo "== $rn"; "$@" > "$OUT/$rn.log" 2>&1 || echo "   (exit $?)"; }
 run trace_default rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- python3 "$B" --steps 30 --warmup 3 $COMMON
 run trace_1ctx    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_1ctx" -- python3 "$B" --steps 30 --warmup 3 --streams 1 $COMMON

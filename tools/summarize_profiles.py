@@ -37,7 +37,7 @@ RUNS = [("default", "`python bench.py --steps 30 --warmup 3` (10 sweeps per laun
         ("nested", "`python tools/train_probe.py --steps 10 --nested --M 1` (twisted sweep with the graph kept + its reverse pass)")]
 lines = ["# rocprofv3 summary, round %s" % tag, "",
          "Workload: primate.p N=12 S=898, GTR-init, K=2048 per sweep.  All bench commands carry",
-         "`--no-cpu-baseline --no-parity --min-timed-ms 0`.  Raw tables: `%s_kernel_stats_*.csv`; counters: `%s_merge_pmc.json`." % (tag, tag), ""]
+         "`--no-cpu-baseline --no-parity --no-vi-step --min-timed-ms 0`.  Raw tables: `%s_kernel_stats_*.csv`; counters: `%s_merge_pmc.json`." % (tag, tag), ""]
 for name, what in RUNS:
     st = one("trace_%s/*/*_kernel_stats.csv" % name)
     if not st:
@@ -121,7 +121,7 @@ if acc:
                            "correction": "2*FETCH_SIZE + WRITE_SIZE (KB -> bytes x1024), MI355X_MICROARCH.md HBM section",
                            "alg_bytes_per_launch": alg, "avg_us_in_pmc_pass": us})
     json.dump({"round": tag, "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 10 --warmup 10 "
-               "--streams 1 --no-cpu-baseline --no-parity --min-timed-ms 0 (three passes: SQ counters, FETCH_SIZE, WRITE_SIZE)",
+               "--streams 1 --no-cpu-baseline --no-parity --no-vi-step --min-timed-ms 0 (three passes: SQ counters, FETCH_SIZE, WRITE_SIZE)",
                "launch_shapes": shapes_out}, open(os.path.join(dst, "%s_merge_pmc.json" % tag), "w"), indent=1)
 # ---- twisted proposal: SQ counters per kernel (durations from the un-countered trace_twist pass)
 f = one("pmc_twist/*/*_counter_collection.csv")
@@ -158,6 +158,6 @@ if f:
                        "sq_insts_salu_per_launch": c.get('SQ_INSTS_SALU'), "sq_insts_lds_per_launch": c.get('SQ_INSTS_LDS'),
                        "avg_us_in_trace_pass": us, "note": "averages over the N-1 rank events of a sweep (their launch sizes differ)"})
     json.dump({"round": tag, "command": "rocprofv3 --kernel-trace --pmc <SQ counters> -- python3 bench.py --twisting --M 1 --steps 3 --warmup 1 --streams 1 "
-               "--no-cpu-baseline --no-parity --min-timed-ms 0", "kernels": tw_out}, open(os.path.join(dst, "%s_twist_pmc.json" % tag), "w"), indent=1)
+               "--no-cpu-baseline --no-parity --no-vi-step --min-timed-ms 0", "kernels": tw_out}, open(os.path.join(dst, "%s_twist_pmc.json" % tag), "w"), indent=1)
 open(os.path.join(dst, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
