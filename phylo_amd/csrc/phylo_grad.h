@@ -39,9 +39,11 @@ struct pg_twist {
     double* twpart;                    // [PG_PART][rows] (value-major: pg_twist_finish reads a value of 256 consecutive rows with one
                                        // coalesced load) Pl_bar, Pr_bar, pi_bar of the row's merge, before the factor tau
     double* twnode;                    // [R][K][PG_NODEG] per particle: d_lam_l, d_lam_r terms, Q_bar, pi_bar of its rows
+    double* twslice;                   // [K][slices][PG_NODEG]: partial sums of one rank event when J > 256
     // adjoints of the adopted roots: entries (adopter * N + slot) grouped by node, cut into chunks of PG_XCH
     const int32_t* xent;
     const int32_t *xchunk_node, *xchunk_beg, *xchunk_cnt;
+    const int32_t* xchunk_part;        // per chunk: (first partner slot) | (one past the last) << 16 -- small launches slice the partners
     const int32_t *xnode_id, *xnode_chunk0, *xnode_nchunks;
     double* tpart;                     // [chunks of one rank event][S][4]
     const uint32_t* pair_hist;         // [N][N][32] or NULL: sites per code pair of two coded leaves (pk_pair_hist)
@@ -872,6 +874,9 @@ __global__ __launch_bounds__(256) void pg_twist_finish(pg_args a, int r) {
     const int k0 = blockIdx.x * KB;
     const int kb = a.K - k0 < KB ? a.K - k0 : KB;            // particles of this workgroup
     const size_t row0 = (size_t)a.tw.joff[r] + (size_t)k0 * J;
+    // J > 256 (many sub-samples): gridDim.y slices of 256 rows per particle, summed afterwards by pg_twist_finish_sum -- with few
+    // particles (the K = 32..64 of the reference's experiments) one workgroup per particle walking 660 rows left the GPU empty
+    const int nsl = (int)gridDim.y, sl = (int)blockIdx.y;
     const double ll = a.lam_l[r], lr = a.lam_r[r];
     double Q[16];
 #pragma unroll
@@ -879,8 +884,8 @@ __global__ __launch_bounds__(256) void pg_twist_finish(pg_args a, int r) {
     double tot[PG_NODEG];                                     // J > 256: a thread keeps the sum of its rows j = tid, tid + 256, ...
 #pragma unroll
     for (int i = 0; i < PG_NODEG; ++i) tot[i] = 0.0;
-    const int nrows = kb * J;
-    for (int t0 = 0; t0 < (J >= 256 ? J : 256); t0 += 256) {
+    const int nrows = nsl > 1 ? (J < (sl + 1) * 256 ? J : (sl + 1) * 256) : kb * J;
+    for (int t0 = sl * 256; t0 < (nsl > 1 ? (sl + 1) * 256 : (J >= 256 ? J : 256)); t0 += 256) {
         const int t = t0 + (int)threadIdx.x;
         double res[PG_NODEG];
 #pragma unroll
@@ -926,8 +931,17 @@ __global__ __launch_bounds__(256) void pg_twist_finish(pg_args a, int r) {
         const int kl = o / PG_NODEG, v = o - kl * PG_NODEG;
         double acc = 0.0;
         for (int j = 0; j < span; ++j) acc = acc + sh[v][kl * span + j];
-        a.tw.twnode[((size_t)r * a.K + k0 + kl) * PG_NODEG + v] = acc;
+        if (nsl > 1) a.tw.twslice[((size_t)(k0 + kl) * nsl + sl) * PG_NODEG + v] = acc;
+        else a.tw.twnode[((size_t)r * a.K + k0 + kl) * PG_NODEG + v] = acc;
     }
+}
+__global__ __launch_bounds__(256) void pg_twist_finish_sum(pg_args a, int r, int nsl) {
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= a.K * PG_NODEG) return;
+    const int k = o / PG_NODEG, v = o - k * PG_NODEG;
+    double acc = 0.0;
+    for (int s = 0; s < nsl; ++s) acc = acc + a.tw.twslice[((size_t)k * nsl + s) * PG_NODEG + v];
+    a.tw.twnode[((size_t)r * a.K + k) * PG_NODEG + v] = acc;
 }
 
 // grid (chunks of rank event r, groups of 256 sites): a thread owns one site of the chunk's node x and walks the chunk's
@@ -935,6 +949,7 @@ __global__ __launch_bounds__(256) void pg_twist_finish(pg_args a, int r) {
 __global__ __launch_bounds__(256) void pg_twist_xchunks(pg_args a, int r, int chunk0) {
     const int ci = blockIdx.x, c = chunk0 + ci;
     const int x = a.tw.xchunk_node[c], beg = a.tw.xchunk_beg[c], cnt = a.tw.xchunk_cnt[c];
+    const int p0 = a.tw.xchunk_part[c] & 0xffff, p1 = a.tw.xchunk_part[c] >> 16;
     const int s = blockIdx.y * 256 + threadIdx.x;
     const bool live = s < a.S;
     const size_t soff = (size_t)(live ? s : a.S - 1) * 4;
@@ -948,7 +963,7 @@ __global__ __launch_bounds__(256) void pg_twist_xchunks(pg_args a, int r, int ch
         const int kp = enc / a.N, i = enc - kp * a.N;
         const int32_t* ro = a.tw.roots_ad + ((size_t)r * a.K + kp) * a.N;
         const size_t row0 = (size_t)a.tw.joff[r] + (size_t)kp * J;
-        for (int i2 = 0; i2 < n; ++i2) {
+        for (int i2 = p0; i2 < p1; ++i2) {
             if (i2 == i) continue;
             const int side = i > i2 ? 1 : 0;                  // x is the right child of the look-ahead merge
             const int tp = side ? pg_pair_index(i2, i, n) : pg_pair_index(i, i2, n);
@@ -991,6 +1006,14 @@ __global__ __launch_bounds__(256) void pg_twist_xsum(pg_args a, int node0, int c
     if (e >= row) return;
     double* dst = a.adj + (size_t)(x - a.N) * row + e;
     double v = *dst;
-    for (int c = 0; c < nc; ++c) v = v + a.tw.tpart[(size_t)(c0 + c) * row + e];
+    const double* src = a.tw.tpart + (size_t)c0 * row + e;
+    for (int cb = 0; cb < nc; cb += 8) {                     // eight chunk rows in flight, added in order
+        double q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = src[(size_t)(cb + u < nc ? cb + u : nc - 1) * row];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (cb + u < nc) v = v + q[u];
+    }
     *dst = v;
 }

@@ -1477,6 +1477,10 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         g.tw.tw_b = c->d_htw_b; g.tw.tw_P = c->d_htw_P; g.tw.pot = c->d_hpot; g.tw.chosen = c->d_hchosen;
         g.tw.tau = c->d_tau; g.tw.ctw = c->d_ctw; g.tw.twpart = c->d_twpart; g.tw.twnode = c->d_twnode;
         g.tw.pair_hist = (c->codes_valid && c->hist_ready) ? c->d_pair_hist : nullptr;
+        const size_t J0 = (size_t)((N * (N - 1)) / 2) * c->last_M;
+        void* sl = nullptr;
+        CHK(scratch_get(c, 4, (size_t)K * ((J0 + 255) / 256) * PG_NODEG * 8, &sl));
+        g.tw.twslice = (double*)sl;
     }
     HIPCHK(c, hipEventRecord(c->evb0, c->stream));
     const int nrk = cdiv((long)R * K, 256);
@@ -1501,9 +1505,15 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         for (int r = 0; r < R; ++r) {
             const int Jr = (((N - r) * (N - r - 1)) / 2) * c->last_M;
             const int KB = Jr >= 256 ? 1 : 256 / Jr;
-            hipLaunchKernelGGL(pg_twist_finish, dim3(cdiv(K, KB)), dim3(256), 0, c->stream, g, r);
+            const int nsl = Jr > 256 ? cdiv(Jr, 256) : 1;
+            hipLaunchKernelGGL(pg_twist_finish, dim3(cdiv(K, KB), nsl), dim3(256), 0, c->stream, g, r);
             CHK(launch_check(c, "pg_twist_finish"));
             ++tw_launches;
+            if (nsl > 1) {
+                hipLaunchKernelGGL(pg_twist_finish_sum, dim3(cdiv((long)K * PG_NODEG, 256)), dim3(256), 0, c->stream, g, r, nsl);
+                CHK(launch_check(c, "pg_twist_finish_sum"));
+                ++tw_launches;
+            }
         }
         HIPCHK(c, hipMemsetAsync(c->d_adj, 0, (size_t)R * K * S * 4 * 8, c->stream));   // pg_twist_xsum accumulates, pg_nodes starts from it
         tw_launches += 3;
@@ -1571,7 +1581,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     size_t n_xent = 0, n_xchunks = 0, n_xnodes = 0;
     if (twist) {
         const int32_t* rad = c->h_rad_p;                            // pinned copy made when the sweep ended
-        std::vector<int32_t> xent, xc_node, xc_beg, xc_cnt, xn_id, xn_c0, xn_nc;
+        std::vector<int32_t> xent, xc_node, xc_beg, xc_cnt, xc_part, xn_id, xn_c0, xn_nc;
         std::vector<int32_t> cnt, first;
         for (int r = 0; r < R; ++r) {
             ev_chunk0[r] = (int32_t)xc_node.size();
@@ -1595,17 +1605,35 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
                     const int x = tab[(size_t)k * N + i];
                     if (x >= N) xent[base + (size_t)first[x - N]++] = k * N + i;
                 }
+            // chunk shape of this rank event: enough workgroups to fill the GPU, not more rows than pg_twist_xsum should add per node.
+            // Many entries (large K): up to PG_XCH entries per chunk, all partner slots.  Few entries (the K = 32..64 of the
+            // reference's experiments): one entry per chunk and the n - 1 partner slots cut into slices, or a chunk is one thread's
+            // walk over (n - 1) M merges per site, a few hundred microseconds with M = 10.
+            const long total_ent = cnt[nn_r];
+            const long target = 2048 / cdiv(S, 256) > 64 ? 2048 / cdiv(S, 256) : 64;
+            int xch = (int)((total_ent + target - 1) / target);
+            xch = xch < 1 ? 1 : (xch > PG_XCH ? PG_XCH : xch);
+            int slices = 1;
+            if (xch == 1 && total_ent > 0) {
+                slices = (int)(target / total_ent);
+                slices = slices < 1 ? 1 : (slices > n ? n : slices);
+            }
+            const int pw = (n + slices - 1) / slices;              // partner slots per slice
             for (size_t x = 0; x < nn_r; ++x) {
                 const int m = cnt[x + 1] - cnt[x];
                 if (m == 0) continue;
                 xn_id.push_back((int32_t)(x + N));
                 xn_c0.push_back((int32_t)xc_node.size());
-                xn_nc.push_back((m + PG_XCH - 1) / PG_XCH);
-                for (int b = 0; b < m; b += PG_XCH) {
-                    xc_node.push_back((int32_t)(x + N));
-                    xc_beg.push_back((int32_t)(base + cnt[x] + b));
-                    xc_cnt.push_back(m - b < PG_XCH ? m - b : PG_XCH);
-                }
+                int nc = 0;
+                for (int b = 0; b < m; b += xch)
+                    for (int p0 = 0; p0 < n; p0 += pw) {
+                        xc_node.push_back((int32_t)(x + N));
+                        xc_beg.push_back((int32_t)(base + cnt[x] + b));
+                        xc_cnt.push_back(m - b < xch ? m - b : xch);
+                        xc_part.push_back(p0 | ((p0 + pw < n ? p0 + pw : n) << 16));
+                        ++nc;
+                    }
+                xn_nc.push_back(nc);
             }
             const size_t nch = xc_node.size() - (size_t)ev_chunk0[r];
             if (nch > tw_max_chunks) tw_max_chunks = nch;
@@ -1614,10 +1642,10 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         ev_node0[R] = (int32_t)xn_id.size();
         n_xent = xent.size(); n_xchunks = xc_node.size(); n_xnodes = xn_id.size();
         std::vector<int32_t>& pk = c->h_xlists;
-        pk.resize(n_xent + 3 * n_xchunks + 3 * n_xnodes + 1);
+        pk.resize(n_xent + 4 * n_xchunks + 3 * n_xnodes + 1);
         int32_t* w = pk.data();
         auto put = [&](const std::vector<int32_t>& v) { if (!v.empty()) memcpy(w, v.data(), v.size() * 4); w += v.size(); };
-        put(xent); put(xc_node); put(xc_beg); put(xc_cnt); put(xn_id); put(xn_c0); put(xn_nc);
+        put(xent); put(xc_node); put(xc_beg); put(xc_cnt); put(xc_part); put(xn_id); put(xn_c0); put(xn_nc);
         CHK(scratch_get(c, 6, pk.size() * 4, &d_xlists));
         HIPCHK(c, hipMemcpyAsync(d_xlists, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, c->stream));
         CHK(scratch_get(c, 7, tw_max_chunks * (size_t)S * 4 * 8, &d_tpart));
@@ -1628,6 +1656,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         g.tw.xchunk_node = xl; xl += n_xchunks;
         g.tw.xchunk_beg = xl; xl += n_xchunks;
         g.tw.xchunk_cnt = xl; xl += n_xchunks;
+        g.tw.xchunk_part = xl; xl += n_xchunks;
         g.tw.xnode_id = xl; xl += n_xnodes;
         g.tw.xnode_chunk0 = xl; xl += n_xnodes;
         g.tw.xnode_nchunks = xl;

@@ -290,6 +290,15 @@ def test_twisted_gradient_edge_shapes(N, S, K, M):
     _check_twisted(genome, Q, pi, ll, lr, K=K, M=M, seed=6)
 
 
+def test_twisted_gradient_more_than_256_rows_per_particle():
+    """9 taxa, M = 8: J = 288 sub-samples at the first rank event (pg_twist_finish in slices of 256 rows), few particles (the
+    chunks of pg_twist_xchunks are single entries with sliced partner slots)."""
+    genome = load_dataset('primate_data_wang')['genome'][:, :40]
+    rng = np.random.default_rng(35)
+    Q, pi, ll, lr = _model(rng, genome.shape[0], spread=0.2, lam=2.3)
+    _check_twisted(genome, Q, pi, ll, lr, K=6, M=8, seed=3)
+
+
 def test_twisted_gradient_many_taxa():
     genome = load_dataset('hohna_data_1')['genome'][:14, :70]
     rng = np.random.default_rng(33)
