@@ -1100,10 +1100,9 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             ta.pair_hist = c->codes_valid ? c->d_pair_hist : nullptr;
             ta.codes = c->codes_valid ? c->d_leaf_codes : nullptr;
             ta.bl_r = c->d_bl + (size_t)r * Kl; ta.br_r = c->d_br + (size_t)r * Kl;
-            hipLaunchKernelGGL(pk_twist_adopt, dim3(K), dim3(64), 0, c->stream, ta);
-            CHK(launch_check(c, "pk_twist_adopt"));
-            hipLaunchKernelGGL(pk_twist_draws, dim3(cdiv(2L * Kl * ta.J, 64)), dim3(64), 0, c->stream, ta, (const double*)c->d_Q, c->jc);
-            CHK(launch_check(c, "pk_twist_draws"));
+            ta.own_tables = c->comm.transport == 0 ? 1 : 0;
+            hipLaunchKernelGGL(pk_twist_adopt_draws, dim3(K + cdiv(2L * Kl * ta.J, 64)), dim3(64), 0, c->stream, ta, (const double*)c->d_Q, c->jc);
+            CHK(launch_check(c, "pk_twist_adopt_draws"));
             if (ta.pair_hist) {                            // coded leaf-leaf pairs: 25 code pairs per row instead of S sites
                 hipLaunchKernelGGL(pk_twist_potentials_ll, dim3((ta.J + 7) / 8, Kl), dim3(256), 0, c->stream, ta);
                 CHK(launch_check(c, "pk_twist_potentials_ll"));
@@ -1121,8 +1120,10 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                 double* rows[1] = {c->d_chosen};
                 CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, (size_t)Kl, c->stream, &c->err));
             }
-            hipLaunchKernelGGL(pk_twist_tables, dim3(cdiv(K, 128)), dim3(128), 0, c->stream, ta);
-            CHK(launch_check(c, "pk_twist_tables"));
+            if (!ta.own_tables) {
+                hipLaunchKernelGGL(pk_twist_tables, dim3(cdiv(K, 128)), dim3(128), 0, c->stream, ta);
+                CHK(launch_check(c, "pk_twist_tables"));
+            }
             launches += 5;
         } else if (c->run.book_mat && r > 0) {
             b.rdraw = c->d_rdraw + (size_t)r * K;

@@ -1422,6 +1422,7 @@ struct pk_twist_args {
     const uint32_t* pair_hist;       // [N][N][32] or NULL: sites per code pair (c_l * 5 + c_r) of two coded leaves
     const uint8_t* codes;            // [N][S] leaf codes or NULL: set when the DATA is coded (contracts v3, v4), whichever
                                      // access path the merge uses
+    int own_tables;                  // pk_twist_choose also writes its particle's new root table (one GPU)
 };
 
 // sites per code pair of every ordered pair of coded leaves: grid (N, N).  Integer LDS atomics (exact).
@@ -1437,9 +1438,9 @@ __global__ __launch_bounds__(256) void pk_pair_hist(const uint8_t* __restrict__ 
     if (tid < 32) hist[((size_t)a * N + b) * 32 + tid] = h[tid];
 }
 
-__global__ __launch_bounds__(64) void pk_twist_adopt(const pk_twist_args ta) {
+__device__ __forceinline__ void pk_twist_adopt_body(const pk_twist_args& ta, int kg) {
     const pk_rank_args& a = ta.a;
-    const int kg = blockIdx.x, lane = threadIdx.x, N = a.N, n = a.n;
+    const int lane = threadIdx.x, N = a.N, n = a.n;
     int anc = kg;
     if (a.r > 0) {
         const pm_u32x4 x = pm_philox4x32((uint32_t)kg, (uint32_t)a.r, PM_STREAM_RESAMPLE, 0u, a.seed);
@@ -1458,9 +1459,10 @@ __global__ __launch_bounds__(64) void pk_twist_adopt(const pk_twist_args ta) {
     }
 }
 
-__global__ __launch_bounds__(64) void pk_twist_draws(const pk_twist_args ta, const double* __restrict__ Q, int jc) {
+__global__ __launch_bounds__(64) void pk_twist_adopt(const pk_twist_args ta) { pk_twist_adopt_body(ta, blockIdx.x); }
+
+__device__ __forceinline__ void pk_twist_draws_body(const pk_twist_args& ta, const double* __restrict__ Q, int jc, long t) {
     const pk_rank_args& a = ta.a;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2L * a.Kloc * ta.J) return;
     const int side = (int)(t & 1);
     const long i = t >> 1;
@@ -1475,6 +1477,14 @@ __global__ __launch_bounds__(64) void pk_twist_draws(const pk_twist_args ta, con
     double* out = ta.tw_P + i * 32 + side * 16;
 #pragma unroll
     for (int u = 0; u < 16; ++u) out[u] = p[u];
+}
+__global__ __launch_bounds__(64) void pk_twist_draws(const pk_twist_args ta, const double* __restrict__ Q, int jc) {
+    pk_twist_draws_body(ta, Q, jc, (long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// adoption (one wave per particle) and the draws (independent of it) in one launch: blocks [0, K) adopt, the rest draw
+__global__ __launch_bounds__(64) void pk_twist_adopt_draws(const pk_twist_args ta, const double* __restrict__ Q, int jc) {
+    if ((int)blockIdx.x < ta.a.K) pk_twist_adopt_body(ta, blockIdx.x);
+    else pk_twist_draws_body(ta, Q, jc, (long)(blockIdx.x - ta.a.K) * 64 + threadIdx.x);
 }
 
 // one (pair, sub-sample) row of potentials for my canonical column: sites tid, tid + 256, ...
@@ -2059,6 +2069,20 @@ __global__ __launch_bounds__(64) void pk_twist_choose(const pk_twist_args ta) {
     a.merges[((size_t)a.r * a.Kloc + k) * 2 + 1] = ir;
     const double* P = ta.tw_P + ((size_t)k * J + jsel) * 32;
     for (int u = 0; u < 32; ++u) ta.Pmat_r[(size_t)k * 32 + u] = P[u];
+    if (ta.own_tables) {                                     // one GPU: my own new root table (pk_twist_tables otherwise)
+        int p = 0;
+        for (int i = n - 1; i >= 0; --i) {
+            if (i == il || i == ir) continue;
+            a.roots_new[(size_t)kg * N + p] = ro[i];
+            a.cnt_new[(size_t)kg * N + p] = co[i];
+            a.rootll_new[(size_t)kg * N + p] = rl[i];
+            if (a.pos_hist) a.pos_hist[(size_t)kg * N + i] = p;
+            ++p;
+        }
+        if (a.pos_hist) { a.pos_hist[(size_t)kg * N + il] = -1; a.pos_hist[(size_t)kg * N + ir] = -1; }
+        a.roots_new[(size_t)kg * N + p] = N + a.r * a.K + kg;
+        a.cnt_new[(size_t)kg * N + p] = co[il] + co[ir];
+    }
 }
 
 __global__ void pk_twist_tables(const pk_twist_args ta) {
