@@ -776,7 +776,7 @@ __device__ __forceinline__ void pg_pbar_site(const double (&x1)[4], const double
 
 // one wave per row (4 rows per workgroup).  Rows of two coded leaves are left to pg_twist_pbar_ll.
 // The 36 sums over the wave's 64 lanes go through LDS, 12 at a time: lane (q, part) adds 16 of the 64 values of sum q.
-__global__ __launch_bounds__(256) void pg_twist_pbar(pg_args a) {
+__global__ __launch_bounds__(256, 4) void pg_twist_pbar(pg_args a) {
     __shared__ double red[4][12][PG_RED_STRIDE];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

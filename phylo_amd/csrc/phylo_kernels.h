@@ -1343,7 +1343,7 @@ __device__ __forceinline__ void pk_merge_epilogue(const pk_rank_args& a, int k, 
     a.logw_r[kg] = lw;
 }
 
-__global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge(const pk_rank_args a) {
+__global__ __launch_bounds__(PK_COLS, 5) void pk_rank_merge(const pk_rank_args a) {
     __shared__ double cols[PK_COLS];
     __shared__ double sh4[4];
     __shared__ __attribute__((aligned(16))) double tabL[5][4], tabR[5][4];
@@ -1841,7 +1841,7 @@ __global__ __launch_bounds__(256) void pk_twist_potentials_ll(const pk_twist_arg
     }
 }
 
-__global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist_args ta) {
+__global__ __launch_bounds__(PK_COLS, 6) void pk_twist_potentials(const pk_twist_args ta) {
     __shared__ double cols[PK_TWIST_LDS_ROWS][PK_COLS];
     __shared__ __attribute__((aligned(16))) double Psh[PK_TWIST_LDS_ROWS][32];
     __shared__ __attribute__((aligned(16))) double tab[PK_TWIST_LDS_ROWS][2][5][4];
@@ -1924,7 +1924,7 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_twist_potentials(const pk_twist
             const bool cR = a.leaf_codes && idr < a.N;
             double Pl[16], Pr[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { Pl[u] = pk_uniform(Psh[q][u]); Pr[u] = Psh[q][16 + u]; }   // P_l in SGPRs
+            for (int u = 0; u < 16; ++u) { Pl[u] = pk_uniform(Psh[q][u]); Pr[u] = pk_uniform(Psh[q][16 + u]); }   // P_l in SGPRs
             pm_lp col = pm_lp_init();
             const uint8_t* Lc = a.leaf_codes + (cL ? (size_t)idl * a.S : 0);
             const uint8_t* Rc = a.leaf_codes + (cR ? (size_t)idr * a.S : 0);
