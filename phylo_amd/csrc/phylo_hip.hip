@@ -1127,14 +1127,13 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             launches += 5;
         } else if (c->run.book_mat && r > 0) {
             b.rdraw = c->d_rdraw + (size_t)r * K;
-            const int grouped = Kl > 8192 ? 1 : 0;
-            const int mat_blocks = grouped ? K / PK_MAT_GROUP : K;
+            const int mat_blocks = K;
             if (N <= 16) {
                 const int bb = cdiv(K, PK_COLS / 16);
-                hipLaunchKernelGGL(pk_rank_book_mat<16>, dim3(bb + mat_blocks), dim3(PK_COLS), lds * (PK_COLS / 16), c->stream, b, bb, grouped);
+                hipLaunchKernelGGL(pk_rank_book_mat<16>, dim3(bb + mat_blocks), dim3(PK_COLS), lds * (PK_COLS / 16), c->stream, b, bb);
             } else {
                 const int bb = cdiv(K, PK_COLS / 32);
-                hipLaunchKernelGGL(pk_rank_book_mat<32>, dim3(bb + mat_blocks), dim3(PK_COLS), lds * (PK_COLS / 32), c->stream, b, bb, grouped);
+                hipLaunchKernelGGL(pk_rank_book_mat<32>, dim3(bb + mat_blocks), dim3(PK_COLS), lds * (PK_COLS / 32), c->stream, b, bb);
             }
             CHK(launch_check(c, "pk_rank_book_mat"));
             ++launches;

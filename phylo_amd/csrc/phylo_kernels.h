@@ -1125,12 +1125,10 @@ __global__ __launch_bounds__(PK_COLS) void pk_materialize_by_draws(const pk_rank
 }
 
 template <int LP>
-__global__ __launch_bounds__(PK_COLS) void pk_rank_book_mat(const pk_rank_args a, int book_blocks, int grouped) {
+__global__ __launch_bounds__(PK_COLS, 5) void pk_rank_book_mat(const pk_rank_args a, int book_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x >= book_blocks) {
-        const int b = (int)blockIdx.x - book_blocks;
-        if (grouped) pk_mat_by_thresholds_grouped(a, b * PK_MAT_GROUP);
-        else pk_mat_by_thresholds(a, b);
+    if ((int)blockIdx.x >= book_blocks) {                 // (one workgroup per particle: the launch is a single sweep's)
+        pk_mat_by_thresholds(a, (int)blockIdx.x - book_blocks);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, sub = tid / LP, sl = tid & (LP - 1);
