@@ -181,7 +181,17 @@ __global__ __launch_bounds__(64) void pg_G(pg_args a) {
         const int32_t* idx = a.ad_idx + (size_t)(r + 1) * a.K;
         const int beg = off[k], end = off[k + 1];
         if (end > beg) {
-            for (int j = beg + lane; j < end; j += 64) sub = sub + a.om[(size_t)(r + 1) * a.K + idx[j]];
+            for (int j0 = beg + lane; j0 < end; j0 += 256) {       // four adopters per lane in flight (index -> weight)
+                int ix[4];
+                double w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ix[u] = idx[j0 + 64 * u < end ? j0 + 64 * u : end - 1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w[u] = a.om[(size_t)(r + 1) * a.K + ix[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + 64 * u < end) sub = sub + w[u];
+            }
             sub = pg_wave_sum(sub);
         }
     }
@@ -208,11 +218,30 @@ __global__ __launch_bounds__(256) void pg_coeff(pg_args a, int r) {
     if (cnt > 0) {
         const int32_t* idx = a.ad_idx + (size_t)(r + 1) * a.K + off;
         const size_t base = (size_t)(r + 1) * a.K;
-        for (int j = lane; j < cnt; j += 64) {
-            const size_t row = (base + idx[j]) * a.N;
-            const int p = a.pos[row + slot];
-            if (p >= 0) v = v + a.C[row + p];
-            if (a.twist) v = v + a.tw.ctw[row + slot];      // the adopter's potentials subtract post() of every adopted root
+        // three dependent loads per adopter (index -> position -> coefficient): four adopters per lane in flight, each level's
+        // loads issued together (clamped index: no branch around a load); added in the same order as one at a time
+        for (int j0 = lane; j0 < cnt; j0 += 256) {
+            size_t row[4];
+            int p[4];
+            double cv[4], tv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 64 * u < cnt ? j0 + 64 * u : cnt - 1;
+                row[u] = (base + idx[j]) * a.N;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                p[u] = a.pos[row[u] + slot];
+                tv[u] = a.twist ? a.tw.ctw[row[u] + slot] : 0.0;   // the adopter's potentials subtract post() of every adopted root
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cv[u] = a.C[row[u] + (p[u] >= 0 ? p[u] : 0)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + 64 * u < cnt) {
+                    if (p[u] >= 0) v = v + cv[u];
+                    if (a.twist) v = v + tv[u];
+                }
         }
         v = pg_wave_sum(v);
     }
