@@ -46,7 +46,8 @@ enum {
     PHYLO_QUIRK_Q1_RAW_Q = 1u << 0,    /* weight subtracts q = 1/C(n,2) itself, not log q (vcsmc.py:298,392).
                                           Set = as the reference.  */
     PHYLO_TWISTING = 1u << 1,          /* twisted/nested proposal of vncsmc.py:295-416 (uses M)          */
-    PHYLO_TIME_KERNELS = 1u << 2,      /* bracket every merge launch with HIP events (profiling runs)    */
+    PHYLO_TIME_KERNELS = 1u << 2,      /* bracket the dominant launch of every rank event with HIP events: the merge, or the
+                                          look-ahead potentials of a twisted sweep (profiling runs; phylo_stats.merge_ms) */
     PHYLO_EAGER_NODES = 1u << 3,       /* always store every new node's partial likelihoods.  Default with the plain
                                           proposal (one GPU: always; sharded: S >= 8192): only nodes whose creator
                                           survives the next resampling are written (the rest are dead stores);
