@@ -816,7 +816,7 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     c->swept = false;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     // one sweep alone on one GPU with lazy nodes: the adopted nodes are written in the bookkeeping launch (pk_rank_book_mat), found
-    // by the resampling draws, which pk_sweep_draws then leaves in d_rdraw.  Batched sweeps keep the separate launch (measured:
+    // by the resampling draws, which pk_sweep_prologue then leaves in d_rdraw.  Batched sweeps keep the separate launch (measured:
     // 2.62e11 against 2.64e11 units/s with the grouped form of the combined launch: nothing to gain).
     const bool book_mat = lazy && c->world == 1 && c->comm.transport == 0 && !fuse_scan && N <= 32 && S <= 4096 && G == 1 && Kl <= 8192 &&
                           !c->env.separate_materialise && !c->env.book_one_per_wave;

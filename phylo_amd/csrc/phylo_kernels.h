@@ -118,12 +118,6 @@ __device__ __forceinline__ void pk_sweep_draws_body(int t, const double* __restr
 #pragma unroll
     for (int j = 0; j < 16; ++j) out[j] = p[j];
 }
-__global__ __launch_bounds__(64) void pk_sweep_draws(const double* __restrict__ Q, const double* __restrict__ lam_l,
-                                                     const double* __restrict__ lam_r, int jc, uint64_t seed, int R, int K,
-                                                     int k0, double* __restrict__ bl, double* __restrict__ br,
-                                                     double* __restrict__ Pmat, int Kg, const uint64_t* __restrict__ group_seeds) {
-    pk_sweep_draws_body(blockIdx.x * blockDim.x + threadIdx.x, Q, lam_l, lam_r, jc, seed, R, K, k0, bl, br, Pmat, Kg, group_seeds);
-}
 
 // The prologue of a sweep of the plain proposal as ONE launch: the draws above, the initial root tables (pk_init_tables) and the
 // cleared marks of the lazy nodes (was a hipMemsetAsync, i.e. a fill kernel) are independent of one another.
@@ -1055,7 +1049,7 @@ __global__ __launch_bounds__(PK_COLS) void pk_materialize_all(const pk_rank_args
 // Bookkeeping AND the writes of the adopted nodes in one launch (one GPU, lazy nodes, N <= 32).  Launched one after the other
 // they are two dependent launches at their latency floors (7.4 + 5.1 us at K = 2048): pk_materialize_adopted waits for the marks
 // the bookkeeping leaves.  But whether particle k was adopted does not need the bookkeeping: with the K draws of this rank event
-// (written once per sweep by pk_sweep_draws), thr = mulhi64(draw, cdf total) is what the index search compares the cdf with, and k
+// (written once per sweep by pk_sweep_prologue), thr = mulhi64(draw, cdf total) is what the index search compares the cdf with, and k
 // is adopted iff some thr lies in [cdf[k-1], cdf[k]).
 // So workgroups [0, book_blocks) do the packed bookkeeping (256 / LP particles each) while workgroups behind them test the
 // thresholds and write node (r-1, k) where needed:
@@ -1395,8 +1389,8 @@ __global__ void pk_fix_rootll(double* __restrict__ rootll_new, const double* __r
 
 // ================================================================================================
 // T: the twisted / nested proposal (vncsmc.py:295-416, 432-499).  Per rank event:
-//   pk_twist_adopt      resampling index + adoption of the ancestor's root table (no pick yet)
-//   pk_twist_draws      branch lengths and transition matrices of every (particle, pair, sub-sample)
+//   pk_twist_adopt_draws  resampling index + adoption of the ancestor's root table (no pick yet), and -- independent of it, in the
+//                       same launch -- branch lengths and transition matrices of every (particle, pair, sub-sample)
 //   pk_twist_potentials look-ahead potential post(merged) - post(left) - post(right) of every one of them
 //   pk_twist_choose     normalise per particle, draw ONE (pair, sub-sample), weight terms, children
 //   pk_twist_tables     new root tables from the chosen pair (all particles; after the all-gather of the
@@ -1457,8 +1451,6 @@ __device__ __forceinline__ void pk_twist_adopt_body(const pk_twist_args& ta, int
     }
 }
 
-__global__ __launch_bounds__(64) void pk_twist_adopt(const pk_twist_args ta) { pk_twist_adopt_body(ta, blockIdx.x); }
-
 __device__ __forceinline__ void pk_twist_draws_body(const pk_twist_args& ta, const double* __restrict__ Q, int jc, long t) {
     const pk_rank_args& a = ta.a;
     if (t >= 2L * a.Kloc * ta.J) return;
@@ -1475,9 +1467,6 @@ __device__ __forceinline__ void pk_twist_draws_body(const pk_twist_args& ta, con
     double* out = ta.tw_P + i * 32 + side * 16;
 #pragma unroll
     for (int u = 0; u < 16; ++u) out[u] = p[u];
-}
-__global__ __launch_bounds__(64) void pk_twist_draws(const pk_twist_args ta, const double* __restrict__ Q, int jc) {
-    pk_twist_draws_body(ta, Q, jc, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 // adoption (one wave per particle) and the draws (independent of it) in one launch: blocks [0, K) adopt, the rest draw
 __global__ __launch_bounds__(64) void pk_twist_adopt_draws(const pk_twist_args ta, const double* __restrict__ Q, int jc) {
