@@ -818,7 +818,7 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     // one sweep alone on one GPU with lazy nodes: the adopted nodes are written in the bookkeeping launch (pk_rank_book_mat), found
     // by the resampling draws, which pk_sweep_prologue then leaves in d_rdraw.  Batched sweeps keep the separate launch (measured:
     // 2.62e11 against 2.64e11 units/s with the grouped form of the combined launch: nothing to gain).
-    const bool book_mat = lazy && c->world == 1 && c->comm.transport == 0 && !fuse_scan && N <= 32 && S <= 4096 && G == 1 && Kl <= 8192 &&
+    const bool book_mat = lazy && c->world == 1 && c->comm.transport == 0 && !fuse_scan && N <= 64 && S <= 4096 && G == 1 && Kl <= 8192 &&
                           !c->env.separate_materialise && !c->env.book_one_per_wave;
     // sharded with lazy nodes: each owner finds ITS adopted nodes the same way (O(Kloc Kg / 64) comparisons) instead of every rank
     // searching the ancestors of all K particles (pk_all_marks, O(K) on every rank whatever the number of GPUs)
@@ -1131,9 +1131,12 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             if (N <= 16) {
                 const int bb = cdiv(K, PK_COLS / 16);
                 hipLaunchKernelGGL(pk_rank_book_mat<16>, dim3(bb + mat_blocks), dim3(PK_COLS), lds * (PK_COLS / 16), c->stream, b, bb);
-            } else {
+            } else if (N <= 32) {
                 const int bb = cdiv(K, PK_COLS / 32);
                 hipLaunchKernelGGL(pk_rank_book_mat<32>, dim3(bb + mat_blocks), dim3(PK_COLS), lds * (PK_COLS / 32), c->stream, b, bb);
+            } else {                                       // 33..64 taxa (DS3-DS8): one wave per particle, four per workgroup
+                const int bb = cdiv(K, PK_COLS / 64);
+                hipLaunchKernelGGL(pk_rank_book_mat<64>, dim3(bb + mat_blocks), dim3(PK_COLS), lds * (PK_COLS / 64), c->stream, b, bb);
             }
             CHK(launch_check(c, "pk_rank_book_mat"));
             ++launches;

@@ -766,7 +766,7 @@ __device__ __forceinline__ void pk_book_particle(const pk_rank_args& a, int kg, 
 template <int LP>
 __device__ __forceinline__ int pk_cdf_search_group(const uint64_t* cdf, int K, uint64_t R, int sl, int lane) {
     const int gshift = lane & ~(LP - 1);
-    const unsigned long long gmask = (1ull << LP) - 1ull;
+    const unsigned long long gmask = LP == 64 ? ~0ull : ((1ull << (LP & 63)) - 1ull);
     int lo = 0, hi = K;             // invariant: answer in [lo, hi), cdf[hi-1] > thr
     int step = (K + LP - 1) / LP;
     int p = (sl + 1) * step - 1;

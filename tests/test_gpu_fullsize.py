@@ -284,3 +284,22 @@ def test_generic_leaf_row_no_codes(flags):
     for seed in (0, 1, 2):
         check(ctx.sweep(seed, flags=flags), CO.sweep(g, Q, PI, lam, lam, 512, seed), "generic leaves seed %d" % seed)
     ctx.close()
+
+
+@pytest.mark.parametrize("dataset,K", [('hohna_data_3', 200), ('hohna_data_5', 333), ('hohna_data_8', 256)])
+def test_ds_datasets_with_33_to_64_taxa(dataset, K):
+    """DS3 (36 taxa), DS5 (50), DS8 (64): the bookkeeping takes one wave per particle (64 lanes), still in the launch that also
+    writes the adopted nodes.  Bit-exact against the oracle; stored and dead nodes on demand."""
+    g = load_dataset(dataset)['genome']
+    N = g.shape[0]
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    ctx = ctx_for(g, K, Q)
+    for seed in (0, 3):
+        out = ctx.sweep(seed)
+        assert out['stats']['n_launches'] <= 3 * (N - 1) + 2, "bookkeeping and adopted-node writes did not share a launch"
+        ref = CO.sweep(g, Q, PI, lam, lam, K, seed, want_nodes=(seed == 3))
+        check(out, ref, "%s K=%d seed %d" % (dataset, K, seed))
+    for (r, k) in [(0, 0), (N - 2, K - 1), (N // 2, K // 3), (1, int(out['ancestors'][1, 0]))]:
+        assert same_bits(ctx.sweep_node(r, k), ref['nodes'][r, k]), "node (%d,%d)" % (r, k)
+    ctx.close()
