@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(PK_COLS) void pk_materialize_all(const pk_rank_args
     pk_materialize_node(a, rho, a.k0 + blockIdx.x, threadIdx.x, PK_COLS, 0, a.S);
 }
 
-// Bookkeeping AND the writes of the adopted nodes in one launch (one GPU, lazy nodes, N <= 32).  Launched one after the other
+// Bookkeeping AND the writes of the adopted nodes in one launch (one GPU, lazy nodes, N <= 64: 16, 32 or 64 lanes per particle).  Launched one after the other
 // they are two dependent launches at their latency floors (7.4 + 5.1 us at K = 2048): pk_materialize_adopted waits for the marks
 // the bookkeeping leaves.  But whether particle k was adopted does not need the bookkeeping: with the K draws of this rank event
 // (written once per sweep by pk_sweep_prologue), thr = mulhi64(draw, cdf total) is what the index search compares the cdf with, and k
