@@ -1397,8 +1397,8 @@ __global__ void pk_fix_rootll(double* __restrict__ rootll_new, const double* __r
 //                       choices when sharded), remaining roots in DESCENDING slot order (vncsmc.py:305)
 // then the ordinary pk_rank_merge.  Sub-sample j = t*M + m of pair t (lexicographic r1 < r2).
 // ================================================================================================
-#define PK_TWIST_MAX_M 16
-#define PK_TWIST_MAX_J 4096
+#define PK_TWIST_MAX_M 64
+#define PK_TWIST_MAX_J 8192
 #define PK_TWIST_DRAW_BLOCK 0xFFFFFFFFu
 
 struct pk_twist_args {
@@ -1762,7 +1762,7 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_ran
 }
 
 #define PK_TWIST_LDS_ROWS 8              // (pair, sub-sample) rows staged and reduced per pass
-#define PK_TWIST_MAX_ROWS 512            // (N-1) M of one workgroup; C(N,2) M <= PK_TWIST_MAX_J and M <= 16 keep it below 360
+#define PK_TWIST_MAX_ROWS 1024           // (N-1) M of one workgroup
 
 // (leaf row of `code` . P)[j], bit-identical to pk_build_leaf_table
 __device__ __forceinline__ double pk_leaf_entry(const double* __restrict__ P, int code, int j) {

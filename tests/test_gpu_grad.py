@@ -355,3 +355,11 @@ def test_vcsmc_train_nested_takes_optimizer_steps(tmp_path):
     assert not np.array_equal(v.left_branches_param, lam0) and np.all(v.left_branches_param > 0)
     assert not np.allclose(v.Qmatrix, 1 / 3 * (1 - np.eye(4)) - np.eye(4))
     v.close()
+
+
+def test_twisted_gradient_many_sub_samples():
+    """M = 40 on 6 taxa: J = 600 sub-samples per particle at the first rank event (three slices of pg_twist_finish)."""
+    rng = np.random.default_rng(41)
+    genome = _codes_genome(rng, 6, 30)
+    Q, pi, ll, lr = _model(rng, 6)
+    _check_twisted(genome, Q, pi, ll, lr, K=5, M=40, seed=9)

@@ -277,6 +277,7 @@ def test_error_behaviour(small):
     ('primate_data_wang', 16, 3, True),
     ('primate_data', 48, 1, False),             # BASELINE config 2 shape: primate.p, GTR-init, twisting
     ('primate_data', 20, 10, False),            # the reference's default M
+    ('primate_data', 6, 64, False),             # M = K of the reference's commented DS runs (autorun.sh:9-12): J = 4224 sub-samples
 ])
 def test_twisted_sweep_bit_exact_vs_oracle(dataset, K, M, jc):
     """Row T: the twisted / nested proposal of vncsmc.py:295-416."""
@@ -300,7 +301,7 @@ def test_twisted_sweep_bit_exact_vs_oracle(dataset, K, M, jc):
     b = CO.sweep(g, Q, PI, lam, lam, K, 1, jc=jc)
     assert_bit_equal(a['log_weights'], b['log_weights'], "plain sweep after a twisted one")
     with pytest.raises(_ffi.PhyloError):
-        ctx.sweep(0, flags=_ffi.FLAGS_DEFAULT | _ffi.TWISTING, M=17)
+        ctx.sweep(0, flags=_ffi.FLAGS_DEFAULT | _ffi.TWISTING, M=65)
     ctx.close()
     # independent NumPy oracle on a small case
     if K <= 20:
