@@ -711,13 +711,8 @@ __global__ __launch_bounds__(256) void pg_reduce(pg_args a) {
 __device__ __forceinline__ int pg_pair_index(int r1, int r2, int n) { return r1 * (2 * n - r1 - 1) / 2 + (r2 - r1 - 1); }
 
 // one wave per (rank event, particle); dynamic LDS: J_0 doubles
-__global__ __launch_bounds__(64) void pg_twist_tau(pg_args a) {
-    extern __shared__ __attribute__((aligned(16))) char pg_smem[];
-    double* w = reinterpret_cast<double*>(pg_smem);
-    const int t = blockIdx.x, lane = threadIdx.x;
-    const int r = t / a.K, k = t - r * a.K;
-    const int n = a.N - r, M = a.tw.M, J = (n * (n - 1) / 2) * M;
-    const size_t row0 = (size_t)a.tw.joff[r] + (size_t)k * J;
+__device__ __forceinline__ void pg_twist_tau_body(const pg_args& a, double* w, int t, int r, int k, int n, int M, int J, size_t row0) {
+    const int lane = threadIdx.x;
     const double* pot = a.tw.pot + row0;
     double mx = -pm_inf();
     for (int j = lane; j < J; j += 64) {
@@ -756,6 +751,17 @@ __global__ __launch_bounds__(64) void pg_twist_tau(pg_args a) {
         }
         a.tw.ctw[(size_t)t * a.N + x] = -acc;
     }
+}
+__global__ __launch_bounds__(64) void pg_twist_tau(pg_args a) {
+    extern __shared__ __attribute__((aligned(16))) char pg_smem[];
+    const int t = blockIdx.x;
+    const int r = t / a.K, k = t - r * a.K;
+    const int n = a.N - r, M = a.tw.M, J = (n * (n - 1) / 2) * M;
+    const size_t row0 = (size_t)a.tw.joff[r] + (size_t)k * J;
+    // the weights / tau of the particle's J rows: LDS, or (J beyond 8192) the tau rows themselves as the working array; two
+    // instantiations, so that the LDS case keeps LDS instructions
+    if (J <= 8192) pg_twist_tau_body(a, reinterpret_cast<double*>(pg_smem), t, r, k, n, M, J, row0);
+    else pg_twist_tau_body(a, a.tw.tau + row0, t, r, k, n, M, J, row0);
 }
 
 struct pg_rowid { int r, k, j, n, J; };

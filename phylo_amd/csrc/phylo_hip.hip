@@ -126,6 +126,8 @@ struct phylo_ctx {
     int32_t *d_roots_ad = nullptr, *d_cnt_ad = nullptr;
     double *d_rootll_ad = nullptr, *d_chosen = nullptr, *d_tw_b = nullptr, *d_tw_P = nullptr, *d_pot = nullptr;
     size_t tw_capacity = 0;              // in (particle, sub-sample) entries
+    double* d_twbuf = nullptr;           // [Kloc][J] softmax weights of pk_twist_choose when J exceeds what LDS holds
+    size_t twbuf_cap = 0;
     // ... and its history when the graph is kept (PHYLO_TWISTING | PHYLO_KEEP_GRAPH): every rank event's rows
     double *d_htw_b = nullptr, *d_htw_P = nullptr, *d_hpot = nullptr, *d_hchosen = nullptr;   // [rows][2], [rows][32], [rows], [R][K]
     int32_t* d_hroots_ad = nullptr;      // [R][K][N]
@@ -233,6 +235,9 @@ int launch_check(phylo_ctx* ctx, const char* what) {
 }
 
 void free_sweep_state(phylo_ctx* c) {
+    if (c->d_twbuf) (void)hipFree(c->d_twbuf);
+    c->d_twbuf = nullptr;
+    c->twbuf_cap = 0;
     void* tw[] = {c->d_roots_ad, c->d_cnt_ad, c->d_rootll_ad, c->d_chosen, c->d_tw_b, c->d_tw_P, c->d_pot};
     for (void* p : tw)
         if (p) (void)hipFree(p);
@@ -740,6 +745,13 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
         const size_t Jmax = (size_t)(N * (N - 1) / 2) * M;
         if (Jmax > PK_TWIST_MAX_J) return fail(c, PHYLO_EINVAL, "twisting: C(N,2)*M = %zu exceeds %d", Jmax, PK_TWIST_MAX_J);
         if ((N - 1) * M > PK_TWIST_MAX_ROWS) return fail(c, PHYLO_EINVAL, "twisting: (N-1)*M = %d exceeds %d", (N - 1) * M, PK_TWIST_MAX_ROWS);
+        if (Jmax > PK_TWIST_LDS_J && c->twbuf_cap < (size_t)Kl * Jmax) {     // weights of more sub-samples than LDS holds
+            if (c->d_twbuf) (void)hipFree(c->d_twbuf);
+            c->d_twbuf = nullptr;
+            c->twbuf_cap = 0;
+            CHK(dalloc(c, &c->d_twbuf, (size_t)Kl * Jmax));
+            c->twbuf_cap = (size_t)Kl * Jmax;
+        }
         if (!c->d_roots_ad) {
             CHK(dalloc(c, &c->d_roots_ad, (size_t)K * N));
             CHK(dalloc(c, &c->d_cnt_ad, (size_t)K * N));
@@ -1101,6 +1113,8 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             ta.codes = c->codes_valid ? c->d_leaf_codes : nullptr;
             ta.bl_r = c->d_bl + (size_t)r * Kl; ta.br_r = c->d_br + (size_t)r * Kl;
             ta.own_tables = c->comm.transport == 0 ? 1 : 0;
+            ta.wbuf = c->d_twbuf;
+            const size_t rowlist_lds = (((size_t)(N - r - 1) * M * 2) + 15) & ~(size_t)15;
             hipLaunchKernelGGL(pk_twist_adopt_draws, dim3(K + cdiv(2L * Kl * ta.J, 64)), dim3(64), 0, c->stream, ta, (const double*)c->d_Q, c->jc);
             CHK(launch_check(c, "pk_twist_adopt_draws"));
             if (ta.pair_hist) {                            // coded leaf-leaf pairs: 25 code pairs per row instead of S sites
@@ -1109,12 +1123,12 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                 ++launches;
             }
             if (timek)     // a twisted sweep's dominant kernel is this one: PHYLO_TIME_KERNELS stamps it instead of the merge
-                hipExtLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((((size_t)Kl * (N - r - 1) + 7) / 8) * 8)), dim3(PK_COLS), 0, c->stream,
+                hipExtLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((((size_t)Kl * (N - r - 1) + 7) / 8) * 8)), dim3(PK_COLS), rowlist_lds, c->stream,
                                       c->kev[2 * r], c->kev[2 * r + 1], 0, ta);
             else
-                hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((((size_t)Kl * (N - r - 1) + 7) / 8) * 8)), dim3(PK_COLS), 0, c->stream, ta);
+                hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((((size_t)Kl * (N - r - 1) + 7) / 8) * 8)), dim3(PK_COLS), rowlist_lds, c->stream, ta);
             CHK(launch_check(c, "pk_twist_potentials"));
-            hipLaunchKernelGGL(pk_twist_choose, dim3(Kl), dim3(64), (size_t)ta.J * 8, c->stream, ta);
+            hipLaunchKernelGGL(pk_twist_choose, dim3(Kl), dim3(64), (size_t)(ta.J <= PK_TWIST_LDS_J ? ta.J : 0) * 8, c->stream, ta);
             CHK(launch_check(c, "pk_twist_choose"));
             if (c->comm.transport != 0) {
                 double* rows[1] = {c->d_chosen};
@@ -1494,7 +1508,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     int tw_launches = 0;
     if (twist) {
         const size_t J0 = (size_t)((N * (N - 1)) / 2) * c->last_M;
-        hipLaunchKernelGGL(pg_twist_tau, dim3(R * K), dim3(64), J0 * 8, c->stream, g);
+        hipLaunchKernelGGL(pg_twist_tau, dim3(R * K), dim3(64), (J0 <= 8192 ? J0 : 8192) * 8, c->stream, g);   // later rank events have fewer rows and use LDS
         CHK(launch_check(c, "pg_twist_tau"));
         hipLaunchKernelGGL(pg_twist_pbar, dim3((unsigned)((c->h_joff[R] + 3) / 4)), dim3(256), 0, c->stream, g);
         CHK(launch_check(c, "pg_twist_pbar"));

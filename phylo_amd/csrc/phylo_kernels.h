@@ -1397,8 +1397,9 @@ __global__ void pk_fix_rootll(double* __restrict__ rootll_new, const double* __r
 //                       choices when sharded), remaining roots in DESCENDING slot order (vncsmc.py:305)
 // then the ordinary pk_rank_merge.  Sub-sample j = t*M + m of pair t (lexicographic r1 < r2).
 // ================================================================================================
-#define PK_TWIST_MAX_M 64
-#define PK_TWIST_MAX_J 8192
+#define PK_TWIST_MAX_M 1024
+#define PK_TWIST_MAX_J (1 << 20)
+#define PK_TWIST_LDS_J 8192             // sub-samples per particle whose weights live in LDS (pk_twist_choose, pg_twist_tau); more go through wbuf
 #define PK_TWIST_DRAW_BLOCK 0xFFFFFFFFu
 
 struct pk_twist_args {
@@ -1415,6 +1416,7 @@ struct pk_twist_args {
     const uint8_t* codes;            // [N][S] leaf codes or NULL: set when the DATA is coded (contracts v3, v4), whichever
                                      // access path the merge uses
     int own_tables;                  // pk_twist_choose also writes its particle's new root table (one GPU)
+    double* wbuf;                    // [Kloc][J] softmax weights when J > PK_TWIST_LDS_J (else they live in LDS)
 };
 
 // sites per code pair of every ordered pair of coded leaves: grid (N, N).  Integer LDS atomics (exact).
@@ -1762,7 +1764,7 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_ran
 }
 
 #define PK_TWIST_LDS_ROWS 8              // (pair, sub-sample) rows staged and reduced per pass
-#define PK_TWIST_MAX_ROWS 1024           // (N-1) M of one workgroup
+#define PK_TWIST_MAX_ROWS 32767          // (N-1) M of one workgroup: its row list is dynamic LDS, 2 bytes per row
 
 // (leaf row of `code` . P)[j], bit-identical to pk_build_leaf_table
 __device__ __forceinline__ double pk_leaf_entry(const double* __restrict__ P, int code, int j) {
@@ -1833,7 +1835,8 @@ __global__ __launch_bounds__(PK_COLS, 6) void pk_twist_potentials(const pk_twist
     __shared__ __attribute__((aligned(16))) double Psh[PK_TWIST_LDS_ROWS][32];
     __shared__ __attribute__((aligned(16))) double tab[PK_TWIST_LDS_ROWS][2][5][4];
     __shared__ __attribute__((aligned(16))) double vsh[PK_TWIST_LDS_ROWS][5][4];   // contract v4 tables of the staged rows
-    __shared__ short rowlist[PK_TWIST_MAX_ROWS];
+    extern __shared__ __attribute__((aligned(16))) char pk_tw_dyn[];   // dynamic: 2 ((n-1) M rounded up) bytes
+    short* rowlist = reinterpret_cast<short*>(pk_tw_dyn);
     __shared__ int nlist;
     const pk_rank_args& a = ta.a;
     const int n = a.n, M = ta.M, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1960,10 +1963,10 @@ __global__ __launch_bounds__(PK_COLS, 6) void pk_twist_potentials(const pk_twist
 
 // one wave per local particle: softmax over its J potentials, one categorical draw (integer CDF), the weight
 // terms of vncsmc.py:472-491 for the chosen pair.
-__global__ __launch_bounds__(64) void pk_twist_choose(const pk_twist_args ta) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// (the body is instantiated twice, with w in LDS and with w in global memory: a pointer selected at run time would turn every
+//  access of the common LDS case into a flat access)
+__device__ __forceinline__ void pk_twist_choose_body(const pk_twist_args& ta, double* w /*[J]*/) {
     const pk_rank_args& a = ta.a;
-    double* w = reinterpret_cast<double*>(smem);             // [J]
     const int k = blockIdx.x, kg = a.k0 + k, lane = threadIdx.x, n = a.n, N = a.N, J = ta.J, M = ta.M;
     const double* pot = ta.pot + (size_t)k * J;
     double mx = -pm_inf();
@@ -2070,6 +2073,11 @@ __global__ __launch_bounds__(64) void pk_twist_choose(const pk_twist_args ta) {
         a.roots_new[(size_t)kg * N + p] = N + a.r * a.K + kg;
         a.cnt_new[(size_t)kg * N + p] = co[il] + co[ir];
     }
+}
+__global__ __launch_bounds__(64) void pk_twist_choose(const pk_twist_args ta) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (ta.J <= PK_TWIST_LDS_J) pk_twist_choose_body(ta, reinterpret_cast<double*>(smem));
+    else pk_twist_choose_body(ta, ta.wbuf + (size_t)blockIdx.x * ta.J);
 }
 
 __global__ void pk_twist_tables(const pk_twist_args ta) {

@@ -363,3 +363,12 @@ def test_twisted_gradient_many_sub_samples():
     genome = _codes_genome(rng, 6, 30)
     Q, pi, ll, lr = _model(rng, 6)
     _check_twisted(genome, Q, pi, ll, lr, K=5, M=40, seed=9)
+
+
+def test_twisted_gradient_more_sub_samples_than_lds_holds():
+    """20 taxa, M = 44: J = 8360 > 8192 sub-samples at the first rank event (pg_twist_tau works in the tau rows, pk_twist_choose in
+    its global weight buffer)."""
+    genome = load_dataset('hohna_data_1')['genome'][:20, :8]
+    rng = np.random.default_rng(43)
+    Q, pi, ll, lr = _model(rng, genome.shape[0], spread=0.2, lam=2.3)
+    _check_twisted(genome, Q, pi, ll, lr, K=2, M=44, seed=4)

@@ -278,6 +278,7 @@ def test_error_behaviour(small):
     ('primate_data', 48, 1, False),             # BASELINE config 2 shape: primate.p, GTR-init, twisting
     ('primate_data', 20, 10, False),            # the reference's default M
     ('primate_data', 6, 64, False),             # M = K of the reference's commented DS runs (autorun.sh:9-12): J = 4224 sub-samples
+    ('hohna_data_1', 4, 32, False),             # DS1 with M = 32 (autorun.sh:9): J = 11 232 sub-samples, more than LDS holds
 ])
 def test_twisted_sweep_bit_exact_vs_oracle(dataset, K, M, jc):
     """Row T: the twisted / nested proposal of vncsmc.py:295-416."""
@@ -301,10 +302,10 @@ def test_twisted_sweep_bit_exact_vs_oracle(dataset, K, M, jc):
     b = CO.sweep(g, Q, PI, lam, lam, K, 1, jc=jc)
     assert_bit_equal(a['log_weights'], b['log_weights'], "plain sweep after a twisted one")
     with pytest.raises(_ffi.PhyloError):
-        ctx.sweep(0, flags=_ffi.FLAGS_DEFAULT | _ffi.TWISTING, M=65)
+        ctx.sweep(0, flags=_ffi.FLAGS_DEFAULT | _ffi.TWISTING, M=1025)
     ctx.close()
     # independent NumPy oracle on a small case
-    if K <= 20:
+    if K <= 20 and M <= 16:
         ref2 = O.sweep_twisted(g, Q, PI, lam, lam, K, M, 3)
         np.testing.assert_array_equal(out['ancestors'], ref2['ancestors'])
         assert out['logZ'] == pytest.approx(ref2['logZ'], rel=1e-9)
