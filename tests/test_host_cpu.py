@@ -80,3 +80,29 @@ def test_vcsmc_constructor_mirrors_reference_attributes():
     np.testing.assert_allclose(log_double_factorial(np.array([1, 3, 5, 7])), [0, np.log(3), np.log(15), np.log(105)])
     rec = np.array([[1, 1, 2, 4], [3, 1, 1, 1]])
     np.testing.assert_array_equal(v.overcounting_correct(rec), O.overcounting_correct(rec))
+
+
+def test_adoption_from_draws_equals_adoption_from_indices():
+    """What pk_rank_book_mat / pk_materialize_by_draws rely on: particle k is adopted iff some draw threshold
+    thr = mulhi64(draw, total) lies in [cdf[k-1], cdf[k]) -- the same set as the distinct values of the index search
+    (first i with cdf[i] > thr), also with zero weights (empty intervals), NaN / -inf weights and the all-equal case."""
+    from oracle import cpu_ref as O
+    rng = np.random.default_rng(5)
+    cases = [rng.normal(size=257) * 30.0,                       # a few heavy particles, many underflowing to weight 0
+             np.zeros(64),                                      # all equal
+             np.where(rng.random(300) < 0.5, -np.inf, rng.normal(size=300)),
+             np.full(40, -np.inf),                              # no finite weight: uniform integer weights
+             np.r_[np.nan, rng.normal(size=99) * 5.0]]
+    for logw in cases:
+        for step in (1, 7):
+            K = logw.shape[0]
+            wi = O.resample_int_weights(logw)
+            cdf = np.cumsum(wi, dtype=np.uint64)
+            total = int(cdf[-1])
+            x0, x1, _, _ = O.philox4x32(np.arange(K), step, O.STREAM_RESAMPLE, 0, 1234)
+            draws = (x1.astype(np.uint64) << np.uint64(32)) | x0.astype(np.uint64)
+            thr = O.mulhi64(draws, total)
+            lo = np.r_[np.uint64(0), cdf[:-1]]
+            adopted = np.array([bool(np.any((thr >= lo[k]) & (thr < cdf[k]))) for k in range(K)])
+            idx = O.resample_indices(logw, 1234, step)
+            assert np.array_equal(np.flatnonzero(adopted), np.unique(idx))
