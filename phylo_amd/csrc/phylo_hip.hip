@@ -1137,8 +1137,9 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             if (!ta.own_tables) {
                 hipLaunchKernelGGL(pk_twist_tables, dim3(cdiv(K, 128)), dim3(128), 0, c->stream, ta);
                 CHK(launch_check(c, "pk_twist_tables"));
+                ++launches;
             }
-            launches += 5;
+            launches += 3;                                 // adopt + draws, potentials, choose
         } else if (c->run.book_mat && r > 0) {
             b.rdraw = c->d_rdraw + (size_t)r * K;
             const int mat_blocks = K;
