@@ -44,7 +44,7 @@ from phylo_amd.rendezvous import exchange_comm_id  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 N_SIMD = 256 * 4           # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md)
-CLK_HZ = 2.4e9             # max clock; in-kernel s_memtime / s_memrealtime read 2.36-2.39 GHz on this workload (tools/persist_probe.py)
+CLK_HZ = 2.4e9             # max clock; in-kernel s_memtime / s_memrealtime read 2.36-2.39 GHz on this workload (tests/probe_persist.py)
 VALU_ISSUE_CYCLES = 4      # a wave64 VALU instruction occupies its SIMD-32 for 4 cycles at fp64 / single-wave issue rate
 
 
@@ -59,7 +59,7 @@ def parse():
     p.add_argument('--synthetic', default=None, help='N,S : synthetic iid-uniform alignment instead of --dataset')
     p.add_argument('--flat', action='store_true',
                    help='replace every row of the alignment by a gap row [1,1,1,1]: near-uniform weights under JC69, children spread over '
-                        'all earlier nodes (tools/regime_probe.py); the opposite extreme of real data')
+                        'all earlier nodes (tests/probe_regimes.py); the opposite extreme of real data')
     p.add_argument('--eager', action='store_true', help='store every node (PHYLO_EAGER_NODES) instead of lazy nodes')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--streams', type=int, default=0,
@@ -69,7 +69,7 @@ def parse():
                         'up to 10 (plain proposal, small nodes), 1 otherwise')
     p.add_argument('--twisting', action='store_true', help='twisted proposal (vncsmc.py); BASELINE config 2')
     p.add_argument('--M', type=int, default=1, help='sub-samples of the twisted proposal')
-    p.add_argument('--params', default=None, help='.npz with Q, pi, lam_l, lam_r (e.g. trained parameters from tools/regime_probe.py) '
+    p.add_argument('--params', default=None, help='.npz with Q, pi, lam_l, lam_r (e.g. trained parameters from tests/probe_regimes.py) '
                                                   'instead of the untrained model')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true', help='skip the 10-seed comparison with the C oracle')

@@ -1,6 +1,6 @@
 """Random (N, S, K, model, flags, form) draws, GPU against the C oracle, bit for bit; wider ranges than the test suite's 60 draws
 (up to 70 taxa: the 16 / 32 / 64-lane and the wave-per-particle bookkeeping; batched groups; twisting; one-launch form; flat
-weights).  python tools/fuzz_parity.py [seconds] [seed]"""
+weights).  python tests/fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
 import time

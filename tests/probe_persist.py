@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-launch sweep (phylo_persist.h) against the launch-per-rank-event path and the C oracle: bits and device time.
-usage: python tools/persist_probe.py [K] [dataset] [reps]"""
+usage: python tests/probe_persist.py [K] [dataset] [reps]"""
 import os
 import sys
 import time

@@ -8,7 +8,7 @@ nodes write almost nothing and every child row sits in L2.  This tool
   2. runs the sweep THROUGH THE LIBRARY with untrained and trained parameters, lazy and eager nodes, launches and the one-launch
      form, and reports per configuration: distinct ancestors per rank event (= nodes materialised by lazy nodes), device time
      per sweep (hipEvents), units/s; every configuration is also compared bit for bit with the C oracle on seed 0.
-usage: python tools/regime_probe.py [--epochs 40] [--K 2048] [--out gpurun_out/regimes.json] [--params-out profiles/r02_trained_params.npz]
+usage: python tests/probe_regimes.py [--epochs 40] [--K 2048] [--out gpurun_out/regimes.json] [--params-out profiles/r02_trained_params.npz]
 """
 import argparse
 import json

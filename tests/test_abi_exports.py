@@ -46,3 +46,11 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "liboracle" not in src, f
                 assert not re.search(r'#\s*include\s*[<"][^>"]*(oracle|ora_)', src), f
+    # ... nor runner.py, nor anything under tools/ (profiling and probing scripts): the checker is used from tests/, from
+    # __graft_entry__.smoke() and from bench.py's cpu_baseline / parity legs only
+    others = [os.path.join(ROOT, "runner.py")] + [os.path.join(ROOT, "tools", f) for f in os.listdir(os.path.join(ROOT, "tools"))
+                                                   if f.endswith((".py", ".sh"))]
+    for path in others:
+        src = open(path, errors="ignore").read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+        assert "liboracle" not in src, path

@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 B="$REPO/bench.py"
 COMMON="--no-cpu-baseline --no-parity --no-vi-step --min-timed-ms 0 --streams 1 --batch 1 --steps 4 --warmup 2"
 run() { local rn=$1; shift; echo "== $rn"; "$@" > "$OUT/$rn.log" 2>&1 || echo "   (exit $?)"; }
-python3 "$REPO/tools/regime_probe.py" --epochs 40 --out "$OUT/regimes.json" --params-out "$OUT/trained_params.npz" > "$OUT/regime_probe.log" 2>&1
+python3 "$REPO/tests/probe_regimes.py" --epochs 40 --out "$OUT/regimes.json" --params-out "$OUT/trained_params.npz" > "$OUT/regime_probe.log" 2>&1
 for cfg in "flat_lazy:--flat --dataset hohna_data_1 --n_particles 4096 --jcmodel true" \
            "flat_eager:--flat --dataset hohna_data_1 --n_particles 4096 --jcmodel true --eager" \
            "trained_lazy:--params $OUT/trained_params.npz" \

@@ -22,7 +22,7 @@ def one(pattern):
 
 
 lines = ["# Sweeps outside the untrained primate.p regime, round %s" % tag, "",
-         "`tools/regime_probe.py` (library calls, hipEvent median of 24 single sweeps, each configuration bit-exact vs the C oracle on seed 0)",
+         "`tests/probe_regimes.py` (library calls, hipEvent median of 24 single sweeps, each configuration bit-exact vs the C oracle on seed 0)",
          "and `tools/profile_regimes.sh` (rocprofv3, three counter passes per configuration of `bench.py --streams 1 --batch 1 ...`).", ""]
 rj = os.path.join(src, "regimes.json")
 out_json = {"round": tag}
