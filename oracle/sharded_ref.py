@@ -24,6 +24,8 @@ from . import cpu_ref as O
 
 def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, flags=O.QUIRK_Q1_RAW_Q, local_tables=False,
                   lazy=False):
+    """lazy='draws': like lazy=True, but every owner finds ITS adopted nodes from the K draw thresholds (the GPU's
+    pk_materialize_by_draws: k is adopted iff some mulhi64(draw, total) lies in [cdf[k-1], cdf[k])) instead of from the K indices."""
     N, S, A = genome.shape
     Kl = K // world
     k0 = rank * Kl
@@ -61,7 +63,15 @@ def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, f
                 cnt = np.concatenate([p[1] for p in parts])
                 rootll = np.concatenate([p[2] for p in parts])
             if lazy:                                                     # owners write the nodes adopted just now
-                for a_ in sorted(set(int(v) for v in idx)):
+                if lazy == 'draws':
+                    cdf = np.cumsum(O.resample_int_weights(log_weights[r - 1]), dtype=np.uint64)
+                    x0, x1, _, _ = O.philox4x32(np.arange(K), r, O.STREAM_RESAMPLE, 0, seed)
+                    thr = O.mulhi64((x1.astype(np.uint64) << np.uint64(32)) | x0.astype(np.uint64), int(cdf[-1]))
+                    lo = np.r_[np.uint64(0), cdf[:-1]]
+                    adopted = [k for k in range(k0, k0 + Kl) if np.any((thr >= lo[k]) & (thr < cdf[k]))]
+                else:
+                    adopted = sorted(set(int(v) for v in idx))
+                for a_ in adopted:
                     if k0 <= a_ < k0 + Kl and (r - 1, a_) in unwritten:
                         pool[(r - 1, a_)] = unwritten.pop((r - 1, a_))
                 unwritten.clear()                                        # the rest of that rank event's nodes are dead

@@ -76,7 +76,8 @@ def _worker(rank, world, port, K, seed, tmp, local_tables, lazy):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,seed,local_tables,lazy", [(16, 0, False, False), (24, 3, True, False), (24, 5, True, True)])
+@pytest.mark.parametrize("K,seed,local_tables,lazy", [(16, 0, False, False), (24, 3, True, False), (24, 5, True, True),
+                                                      (24, 5, True, 'draws'), (40, 9, True, 'draws')])
 def test_sharded_protocol_world2(K, seed, local_tables, lazy):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() * 7 + K) % 1000
