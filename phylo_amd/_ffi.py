@@ -282,6 +282,16 @@ class Context:
         self._check(self._lib.phylo_comm_allgather(self._h, _ptr(a), C.c_size_t(a.nbytes), _ptr(out)))
         return np.concatenate(list(out), axis=-1)
 
+    def comm_allgather_blob(self, a):
+        """a: the same shape and dtype on every rank -> [world, ...] (one row per rank).  Collective."""
+        a = np.ascontiguousarray(a)
+        world = self.K // self.K_local
+        if world == 1:
+            return a[None]
+        out = np.empty((world,) + a.shape, dtype=a.dtype)
+        self._check(self._lib.phylo_comm_allgather(self._h, _ptr(a), C.c_size_t(a.nbytes), _ptr(out)))
+        return out
+
     def comm_max(self, value):
         v = C.c_double(float(value))
         self._check(self._lib.phylo_comm_max(self._h, C.byref(v)))

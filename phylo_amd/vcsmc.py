@@ -317,7 +317,13 @@ class VCSMC:
         print('================= Dataset shape: KxNxSxA =================')
         print((self.K, self.N, self.S, self.A))
         print('==========================================================')
-        self._context()                                    # fixes the device (and joins the ranks when --n_gpus > 1)
+        ctx = self._context()                              # fixes the device (and joins the ranks when --n_gpus > 1)
+        if getattr(self, '_world', 1) > 1:
+            # every rank takes the optimiser steps redundantly, so all of them must train on the SAME site minibatches; python's
+            # global RNG (unseeded, like the reference) differs from process to process: rank 0's slices are everybody's
+            flat = ctx.comm_allgather_blob(np.asarray(sum(slices, []), dtype=np.int32))[0]
+            cuts = np.cumsum([len(sl) for sl in slices])[:-1]
+            slices = [[int(v) for v in part] for part in np.split(flat, cuts)]
         self.optimizer = train_mod.make_optimizer(getattr(self.args, 'optimizer', ''), self.lr)   # vcsmc.py:488-491
         nested = bool(getattr(self.args, 'nested', False))
         trainer = None

@@ -13,7 +13,8 @@ def main():
     rank, world, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world))
     import random
-    random.seed(3)                                   # batch_slices uses python's global RNG, like the reference
+    random.seed(3 if rank == 0 else 1000 + rank)     # batch_slices uses python's global RNG, like the reference: the
+                                                     # ranks of a sharded run do not share its state, rank 0's slices must win
     import runner
     from phylo_amd.datasets import load_dataset
     from phylo_amd.vcsmc import VCSMC
