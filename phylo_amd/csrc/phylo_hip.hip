@@ -526,6 +526,7 @@ int phylo_set_leaves(phylo_ctx* c, const double* genome) {
         if (ok) HIPCHK(c, hipMemcpy(c->d_leaf_codes, codes.data(), rows, hipMemcpyHostToDevice));
     }
     c->have_leaves = true;
+    c->last_graph = c->last_graph_twist = false;           // ... and to the leaves
     CHK(refresh_leaf_ll(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PHYLO_OK;
@@ -548,6 +549,7 @@ int phylo_set_model(phylo_ctx* c, const double* Q16, const double* pi4, const do
     memcpy(pack.data() + 20 + c->N, lam_r, (size_t)R * 8);
     HIPCHK(c, hipMemcpyAsync(c->d_Q, pack.data(), pack.size() * 8, hipMemcpyHostToDevice, c->stream));
     c->have_model = true;
+    c->last_graph = c->last_graph_twist = false;           // a kept graph belongs to the model it was swept with
     CHK(refresh_leaf_ll(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PHYLO_OK;

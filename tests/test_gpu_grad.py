@@ -111,6 +111,10 @@ def test_backward_needs_graph():
         ctx.sweep(1)
         with pytest.raises(_ffi.PhyloError):
             ctx.sweep_backward()
+        ctx.sweep(1, _ffi.FLAGS_DEFAULT | _ffi.KEEP_GRAPH)
+        ctx.set_model(O.jc_Q(), np.full((1, 4), 0.25), np.full(N - 1, 9.0), np.full(N - 1, 9.0))
+        with pytest.raises(_ffi.PhyloError):             # the kept graph belongs to the model it was swept with
+            ctx.sweep_backward()
 
 
 # ---- the twisted proposal's reverse pass (vncsmc.py:295-416) -----------------------------------------------------
