@@ -249,6 +249,8 @@ class Context:
         self._check(self._lib.phylo_sweep_backward(self._h, _ptr(out['d_lam_l']), _ptr(out['d_lam_r']), _ptr(out['d_pi']),
                                                    _ptr(out['d_Q']), C.byref(st)))
         out['backward_ms'] = st.sweep_ms
+        out['backward_host_ms'] = st.merge_ms          # host time of the integer lists inside backward_ms
+        out['backward_launches'] = st.n_launches
         return out
 
     def debug_stamps(self):

@@ -69,6 +69,11 @@ struct pg_args {
     const int32_t* heavy_first;        // [R K]: first chunk (within its rank event's chunk range) of a heavy node, else -1
     const int32_t *chunk_beg, *chunk_cnt;   // per chunk: first entry of par_idx, number of entries (<= PG_HCHUNK)
     double* cpart;                     // [chunks of one rank event][S][4]
+    const int32_t* slow_flag;          // [R K]: 0: pg_nodes_free; else pg_nodes_rows: (index in slow_idx) << 2 | (bit 0: has parents, bit 1: look-ahead entries)
+    const int32_t* slow_idx;           // the flagged nodes, grouped by rank event (rows form)
+    const unsigned int* mark;          // [R][K] or NULL: node (r, k) was adopted at rank event r + 1 (the lazy sweep's marks)
+    double* slowpart;                  // [flagged nodes][TS][PG_PART] (rows form; else NULL): their partial sums, TS tiles of 256 sites
+    int TS;
     double *om, *G;                    // [R][K]
     double* C;                         // [R][K][N]: coefficient of sum_s log(pi . X) of every root slot after rank event r
     double* part;                      // [R][K][T][PG_PART]
@@ -313,13 +318,21 @@ __device__ __forceinline__ double pg_quad_sum_step(double v) {   // the value of
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ void pg_stage_parents(const pg_args& a, int c0, int nc, double (*shP)[32], int* shE, int* shSib) {
+// par_idx entry: (parent node * 2 + side) | PG_FREE_PARENT when the parent's adjoint row is the own term alone and is not stored
+// (rows form: pg_nodes_free); the gather then recomputes it from alpha_parent (staged in shA)
+#define PG_FREE_PARENT (1 << 30)
+__device__ __forceinline__ double pg_alpha_of(const pg_args& a, int pn) {
+    const int rp = pn / a.K;
+    return a.C[(size_t)pn * a.N + (a.N - rp - 2)];
+}
+__device__ __forceinline__ void pg_stage_parents(const pg_args& a, int c0, int nc, double (*shP)[32], int* shE, int* shSib, double* shA) {
     const int e = threadIdx.x >> 5, q = threadIdx.x & 31;
     if (e < nc) {
         const int enc = a.par_idx[c0 + e];
-        const int pn = enc >> 1, side = enc & 1;
+        const int pn = (enc & (PG_FREE_PARENT - 1)) >> 1, side = enc & 1;
         shP[e][q] = a.Pmat[(size_t)pn * 32 + q];
         if (q == 0) { shE[e] = enc; shSib[e] = a.child[(size_t)pn * 2 + (1 - side)]; }
+        if (q == 1) shA[e] = pg_alpha_of(a, pn);
     }
 }
 
@@ -327,25 +340,38 @@ __device__ __forceinline__ void pg_stage_parents(const pg_args& a, int c0, int n
 // first is used (index clamped, so no branch surrounds a load): a loop with a load inside pays one memory latency per parent, and
 // that -- not bandwidth or arithmetic -- was what pg_parent_chunks and the heavy nodes of pg_nodes cost.
 __device__ __forceinline__ double pg_parent_quad(const pg_args& a, size_t soff, int j, int nc, const double (*shP)[32],
-                                                 const int* shE, const int* shSib, double xb) {
+                                                 const int* shE, const int* shSib, const double* shA, double me, double xb) {
     const size_t row = (size_t)a.S * 4;
     double xpv[PG_PCHUNK], sbv[PG_PCHUNK];
 #pragma unroll
     for (int e = 0; e < PG_PCHUNK; ++e) {
         const int ee = e < nc ? e : nc - 1;
-        xpv[e] = a.adj[(size_t)(shE[ee] >> 1) * row + soff];
+        const int enc = __builtin_amdgcn_readfirstlane(shE[ee]);
+        xpv[e] = 0.0;
+        if (!(enc & PG_FREE_PARENT)) xpv[e] = a.adj[(size_t)(enc >> 1) * row + soff];
         sbv[e] = pg_row(a, shSib[ee])[soff];
     }
+    const double m0 = pg_quad<0>(me), m1 = pg_quad<1>(me), m2 = pg_quad<2>(me), m3 = pg_quad<3>(me);
+    const double pj = a.pi[j];
 #pragma unroll
     for (int e = 0; e < PG_PCHUNK; ++e) {
-        if (e < nc) {                                        // workgroup-uniform
-            const int side = shE[e] & 1;
+        if (e < nc) {                                        // wave-uniform
+            const int enc = __builtin_amdgcn_readfirstlane(shE[e]);
+            const int side = enc & 1;
             const double* Psib = shP[e] + (1 - side) * 16;
             const double* Pme = shP[e] + side * 16;
             const double sb = sbv[e];
             const double b0 = pg_quad<0>(sb), b1 = pg_quad<1>(sb), b2 = pg_quad<2>(sb), b3 = pg_quad<3>(sb);
             const double w = pg_dot4(b0, Psib[j], b1, Psib[4 + j], b2, Psib[8 + j], b3, Psib[12 + j]);
-            const double t = xpv[e] * w;
+            double xp = xpv[e];
+            if (enc & PG_FREE_PARENT) {                      // alpha_p pi / (pi . X_p),  X_p = (me P_me) o (sib P_sib)
+                const double u = pg_dot4(m0, Pme[j], m1, Pme[4 + j], m2, Pme[8 + j], m3, Pme[12 + j]);
+                double lik = pj * (u * w);
+                lik = lik + pg_quad_sum_step<1>(lik);
+                lik = lik + pg_quad_sum_step<2>(lik);
+                xp = shA[e] * pj / lik;
+            }
+            const double t = xp * w;
             const double t0 = pg_quad<0>(t), t1 = pg_quad<1>(t), t2 = pg_quad<2>(t), t3 = pg_quad<3>(t);
             xb = xb + pg_dot4(t0, Pme[j * 4], t1, Pme[j * 4 + 1], t2, Pme[j * 4 + 2], t3, Pme[j * 4 + 3]);
         }
@@ -353,31 +379,50 @@ __device__ __forceinline__ double pg_parent_quad(const pg_args& a, size_t soff, 
     return xb;
 }
 
-// grid (groups of 64 sites, chunks of this rank event): cpart[chunk][s] = sum of the chunk's parent contributions
+// grid (groups of 16 sites, chunks of this rank event): cpart[chunk][s] = sum of the chunk's parent contributions.  The chunk's
+// (up to PG_HCHUNK = 4 PG_PCHUNK) parents are staged at once and each of the four waves gathers its own PG_PCHUNK of them for the
+// same 16 sites, all loads of a wave in flight together; the four partial sums are added in wave order.  (One wave after the
+// other over 64 sites -- the first version -- paid a staging and a gather latency per PG_PCHUNK parents: 19.5 us per launch.)
 __global__ __launch_bounds__(256) void pg_parent_chunks(pg_args a, int chunk0) {
-    __shared__ double shP[PG_PCHUNK][32];
-    __shared__ int shE[PG_PCHUNK];
-    __shared__ int shSib[PG_PCHUNK];
-    const int ci = blockIdx.y;
+    static_assert(PG_HCHUNK == 4 * PG_PCHUNK, "one wave per PG_PCHUNK parents of a chunk");
+    __shared__ double shP[PG_HCHUNK][32];
+    __shared__ int shE[PG_HCHUNK];
+    __shared__ int shSib[PG_HCHUNK];
+    __shared__ double shA[PG_HCHUNK];
+    __shared__ int shMe;
+    __shared__ double shX[4][64];
+    const int ci = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c0 = a.chunk_beg[chunk0 + ci], cnt = a.chunk_cnt[chunk0 + ci];
-    const int s = blockIdx.x * 64 + (threadIdx.x >> 2), j = threadIdx.x & 3;
+    const int s = blockIdx.x * 16 + (lane >> 2), j = lane & 3;
     const bool live = s < a.S;
-    const size_t soff = (size_t)s * 4 + j;
-    double xb = 0.0;
-    for (int st = 0; st < cnt; st += PG_PCHUNK) {
-        const int nc = cnt - st < PG_PCHUNK ? cnt - st : PG_PCHUNK;
-        __syncthreads();
-        pg_stage_parents(a, c0 + st, nc, shP, shE, shSib);
-        __syncthreads();
-        if (live) xb = pg_parent_quad(a, soff, j, nc, shP, shE, shSib, xb);
+    const size_t soff = (size_t)(live ? s : a.S - 1) * 4 + j;
+    for (int i = tid; i < cnt * 32; i += 256) {
+        const int e = i >> 5, q = i & 31;
+        const int enc = a.par_idx[c0 + e];
+        const int pn = (enc & (PG_FREE_PARENT - 1)) >> 1, side = enc & 1;
+        shP[e][q] = a.Pmat[(size_t)pn * 32 + q];
+        if (q == 0) { shE[e] = enc; shSib[e] = a.child[(size_t)pn * 2 + (1 - side)]; }
+        if (q == 1) shA[e] = pg_alpha_of(a, pn);
+        if (i == 2) shMe = a.child[(size_t)pn * 2 + side];   // the node all these are parents of
     }
-    if (live) a.cpart[(size_t)ci * a.S * 4 + soff] = xb;
+    __syncthreads();
+    const int nc = cnt - wv * PG_PCHUNK < PG_PCHUNK ? cnt - wv * PG_PCHUNK : PG_PCHUNK;
+    double xb = 0.0;
+    if (nc > 0) {
+        const double me = pg_row(a, shMe)[soff];
+        xb = pg_parent_quad(a, soff, j, nc, shP + wv * PG_PCHUNK, shE + wv * PG_PCHUNK, shSib + wv * PG_PCHUNK, shA + wv * PG_PCHUNK, me, 0.0);
+    }
+    shX[wv][lane] = xb;
+    __syncthreads();
+    if (wv == 0 && live) a.cpart[(size_t)ci * a.S * 4 + soff] = ((shX[0][lane] + shX[1][lane]) + shX[2][lane]) + shX[3][lane];
 }
 
 // grid (tiles of PG_NT sites, K)
 __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
     __shared__ double shP[PG_PCHUNK][32];
     __shared__ int shE[PG_PCHUNK];
+    __shared__ double shA[PG_PCHUNK];
     __shared__ int shSib[PG_PCHUNK];
     __shared__ double shOwn[32];
     __shared__ double shR[4][9][4];
@@ -392,8 +437,9 @@ __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
     const int hv = a.heavy_first[node];
     const int np = pend - pbeg;
     const int nch = hv >= 0 ? (np + PG_HCHUNK - 1) / PG_HCHUNK : 0;
+    const bool has_x = (a.slow_flag[node] & 2) != 0;
     if (tid < 32) shOwn[tid] = a.Pmat[node * 32 + tid];
-    if (hv < 0 && np > 0) pg_stage_parents(a, pbeg, np, shP, shE, shSib);
+    if (hv < 0 && np > 0) pg_stage_parents(a, pbeg, np, shP, shE, shSib, shA);
     __syncthreads();
     const double* Lrow = pg_row(a, a.child[node * 2]);
     const double* Rrow = pg_row(a, a.child[node * 2 + 1]);
@@ -429,7 +475,7 @@ __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
         const double lik = pg_dot4(p0, x0, p1, x1, p2, x2, p3, x3);
         const double inv = alpha / lik;
         double xb = pj * inv;
-        if (a.twist) xb = xb + orow[soff];                  // what the look-ahead merges of later rank events left (pg_twist_xsum)
+        if (has_x) xb = xb + orow[soff];                    // what the look-ahead merges of later rank events left (pg_twist_xsum)
         acc[8] = __builtin_fma(x, inv, acc[8]);
         if (hv >= 0) {
             const double* cp = a.cpart + (size_t)hv * row + soff;
@@ -441,7 +487,7 @@ __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
             }
             for (; c < nch; ++c) xb = xb + cp[(size_t)c * row];
         } else if (np > 0) {
-            xb = pg_parent_quad(a, soff, j, np, shP, shE, shSib, xb);
+            xb = pg_parent_quad(a, soff, j, np, shP, shE, shSib, shA, x, xb);
         }
         orow[soff] = xb;
         const double L0 = pg_quad<0>(Lj), L1 = pg_quad<1>(Lj), L2 = pg_quad<2>(Lj), L3 = pg_quad<3>(Lj);
@@ -470,116 +516,102 @@ __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
     }
 }
 
-// The same for small nodes (S <= 4096), row form: one workgroup per node, thread = site (sites tid, tid + 256, ...), the node's
-// own matrices in scalar registers, whole 32-byte rows per load, fused multiply-adds, and ONE reduction of the 36 sums per node
-// (through LDS) instead of one per 256-site tile.  The quad form above spends most of its instructions on DPP broadcasts and
-// on reducing 9 sums per lane for every tile; here a site costs about 80 instructions in all.  grid (K), part has one tile (T = 1).
-__global__ __launch_bounds__(256, 4) void pg_nodes_rows(pg_args a, int r) {
-    __shared__ double shP[PG_PCHUNK][32];
-    __shared__ int shE[PG_PCHUNK];
-    __shared__ int shSib[PG_PCHUNK];
-    __shared__ double red[4][12][PG_RED_STRIDE];
-    __shared__ double shW[4][PG_PART];
-    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+// The 36 sums of a node over the 256 threads of its workgroup (fixed order): per wave through its own LDS rows, then the four
+// waves in order; thread t < PG_PART writes sum t.
+struct pg_rows_lds {
+    double red[4][12][PG_RED_STRIDE];
+    double shW[4][PG_PART];
+};
+__device__ __forceinline__ void pg_rows_reduce(const double (&acc)[PG_PART], pg_rows_lds& sh, double* out) {
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t node = (size_t)r * a.K + k;
-    const size_t row = (size_t)a.S * 4;
-    const double alpha = a.C[node * a.N + (a.N - r - 2)];
+    const int q = lane >> 2, part = lane & 3;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) sh.red[wv][i][lane] = acc[b * 12 + i];
+        __builtin_amdgcn_wave_barrier();
+        double v = 0.0;
+        if (q < 12) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v = v + sh.red[wv][q][part + 4 * i];
+        }
+        v = v + pg_quad_sum_step<1>(v);
+        v = v + pg_quad_sum_step<2>(v);
+        if (q < 12 && part == 0) sh.shW[wv][b * 12 + q] = v;
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (tid < PG_PART) out[tid] = ((sh.shW[0][tid] + sh.shW[1][tid]) + sh.shW[2][tid]) + sh.shW[3][tid];
+}
+
+// Nodes nobody merged again -- all but the few adopted ones, of ALL rank events in one launch: one WAVE per node (grid R K / 4;
+// a flagged node's wave leaves at once: pg_nodes_rows takes it).  Their adjoint is the own term alone, alpha pi / (pi . X), so one
+// pass over the sites does everything.  The node's own row is recomputed from the children, (L P_l) o (R P_r) as in the forward
+// merge: the stored row is not read, so the sweep need not have stored it (lazy nodes), and the adjoint row is not written
+// either -- a child that gathers from such a parent recomputes the own term (PG_FREE_PARENT), which costs less than the HBM
+// round trip of the row.  Children are leaves or adopted nodes: a few rows, read by thousands of nodes (L2).  A wave per node, not a workgroup: the chain node -> children -> rows -> 36 sums is latency,
+// and sixteen independent chains per CU hide it where four workgroups did not (132 us per launch at K = 2048, N = 12); the rows
+// of the next 64 sites are loaded while the current ones are used.
+// phase 0 (before the host has built any list; needs the marks of a lazy sweep): the nodes nobody adopted -- no adopters, so
+// alpha = G = omega exactly, and no parents.  phase 1 (after the lists): the adopted nodes without parents.  phase 2: no marks,
+// every node without parents in one launch after the lists.
+__global__ __launch_bounds__(256, 3) void pg_nodes_free(pg_args a, int phase) {
+    __shared__ double red[4][12][PG_RED_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t node = (size_t)blockIdx.x * 4 + wv;
+    if (node >= (size_t)a.R * a.K) return;
+    if (phase == 0) {
+        if (a.mark[node]) return;
+    } else {
+        if (a.slow_flag[node]) return;
+        if (phase == 1 && !a.mark[node]) return;
+    }
+    const int r = (int)(node / (size_t)a.K);
+    const double alpha = phase == 0 ? a.om[node] : a.C[node * a.N + (a.N - r - 2)];
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
-    const int pbeg = a.par_off[node], pend = a.par_off[node + 1];
-    const int hv = a.heavy_first[node];
-    const int np = pend - pbeg;
-    const int nch = hv >= 0 ? (np + PG_HCHUNK - 1) / PG_HCHUNK : 0;
-    if (hv < 0 && np > 0) pg_stage_parents(a, pbeg, np, shP, shE, shSib);
     const double* Pu = a.Pmat + node * 32;
     double Pl[16], Pr[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { Pl[i] = Pu[i]; Pr[i] = Pu[16 + i]; }
-    __syncthreads();
-    const double* Lrow = pg_row(a, a.child[node * 2]);
-    const double* Rrow = pg_row(a, a.child[node * 2 + 1]);
-    const double* xrow = a.pool + node * row;
-    double* orow = a.adj + node * row;
+    const int cl = a.child[node * 2], cr = a.child[node * 2 + 1];
+    const double* Lrow = pg_row(a, cl);
+    const double* Rrow = pg_row(a, cr);
     double acc[PG_PART];
 #pragma unroll
     for (int i = 0; i < PG_PART; ++i) acc[i] = 0.0;
-    // phase A: the adjoint row (own term + parents), written to adj; phase B re-reads it (L2) for the matrix adjoints.  Two loops
-    // keep either phase below 128 registers (one loop: 207, two waves per SIMD).
-    #pragma unroll 1
-    for (int s = tid; s < a.S; s += 256) {
-        const size_t so = (size_t)s * 4;
-        double x[4], xb[4];
+    double Ln[4], Rn[4];
+    {
+        const size_t so = (size_t)(lane < a.S ? lane : a.S - 1) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = xrow[so + i];
-        const double lik = pg_dot4(pi[0], x[0], pi[1], x[1], pi[2], x[2], pi[3], x[3]);
-        const double inv = alpha / lik;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            xb[j] = pi[j] * inv;
-            acc[32 + j] = __builtin_fma(x[j], inv, acc[32 + j]);
-        }
-        if (a.twist) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xb[j] = xb[j] + orow[so + j];
-        }
-        if (hv >= 0) {                                       // chunk sums, eight rows in flight (added in order)
-            const double* cp = a.cpart + (size_t)hv * row + so;
-            for (int c0 = 0; c0 < nch; c0 += 8) {
-                double q[8][4];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int cc = c0 + u < nch ? c0 + u : nch - 1;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) q[u][j] = cp[(size_t)cc * row + j];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (c0 + u < nch) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) xb[j] = xb[j] + q[u][j];
-                    }
-            }
-        } else {
-            for (int e0 = 0; e0 < np; e0 += 4) {             // the light node's own parents, four at a time, loads first
-                double xp[4][4], sb[4][4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int ee = e0 + u < np ? e0 + u : np - 1;
-                    const double* xpp = a.adj + (size_t)(shE[ee] >> 1) * row + so;
-                    const double* sbp = pg_row(a, shSib[ee]) + so;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { xp[u][j] = xpp[j]; sb[u][j] = sbp[j]; }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (e0 + u < np) {
-                        const int e = e0 + u, side = shE[e] & 1;
-                        const double* Psib = shP[e] + (1 - side) * 16;
-                        const double* Pme = shP[e] + side * 16;
-                        double t[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            t[j] = xp[u][j] * pg_dot4(sb[u][0], Psib[j], sb[u][1], Psib[4 + j], sb[u][2], Psib[8 + j], sb[u][3], Psib[12 + j]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            xb[j] = xb[j] + pg_dot4(t[0], Pme[j * 4], t[1], Pme[j * 4 + 1], t[2], Pme[j * 4 + 2], t[3], Pme[j * 4 + 3]);
-                    }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) orow[so + j] = xb[j];
+        for (int i = 0; i < 4; ++i) { Ln[i] = Lrow[so + i]; Rn[i] = Rrow[so + i]; }
     }
     #pragma unroll 1
-    for (int s = tid; s < a.S; s += 256) {                   // (a thread re-reads only what it wrote itself)
-        const size_t so = (size_t)s * 4;
-        double L[4], Rv[4], xb[4];
+    for (int s = lane; s < a.S; s += 64) {
+        double L[4], Rv[4], u[4], v[4], xb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { L[i] = Lrow[so + i]; Rv[i] = Rrow[so + i]; xb[i] = orow[so + i]; }
+        for (int i = 0; i < 4; ++i) { L[i] = Ln[i]; Rv[i] = Rn[i]; }
+        {
+            const size_t sn = (size_t)(s + 64 < a.S ? s + 64 : a.S - 1) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { Ln[i] = Lrow[sn + i]; Rn[i] = Rrow[sn + i]; }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const double u = pg_dot4(L[0], Pl[j], L[1], Pl[4 + j], L[2], Pl[8 + j], L[3], Pl[12 + j]);
-            const double v = pg_dot4(Rv[0], Pr[j], Rv[1], Pr[4 + j], Rv[2], Pr[8 + j], Rv[3], Pr[12 + j]);
-            const double tl = xb[j] * v, tr = xb[j] * u;
+            u[j] = pg_dot4(L[0], Pl[j], L[1], Pl[4 + j], L[2], Pl[8 + j], L[3], Pl[12 + j]);
+            v[j] = pg_dot4(Rv[0], Pr[j], Rv[1], Pr[4 + j], Rv[2], Pr[8 + j], Rv[3], Pr[12 + j]);
+        }
+        const double x0 = u[0] * v[0], x1 = u[1] * v[1], x2 = u[2] * v[2], x3 = u[3] * v[3];
+        const double lik = pg_dot4(pi[0], x0, pi[1], x1, pi[2], x2, pi[3], x3);
+        const double inv = alpha / lik;
+        acc[32] = __builtin_fma(x0, inv, acc[32]); acc[33] = __builtin_fma(x1, inv, acc[33]);
+        acc[34] = __builtin_fma(x2, inv, acc[34]); acc[35] = __builtin_fma(x3, inv, acc[35]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xb[j] = pi[j] * inv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double tl = xb[j] * v[j], tr = xb[j] * u[j];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 acc[i * 4 + j] = __builtin_fma(L[i], tl, acc[i * 4 + j]);
@@ -588,8 +620,9 @@ __global__ __launch_bounds__(256, 4) void pg_nodes_rows(pg_args a, int r) {
         }
     }
     const int q = lane >> 2, part = lane & 3;
+    double* out = a.part + node * PG_PART;
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {                            // per wave through its own LDS rows, then the four waves in order
+    for (int b = 0; b < 3; ++b) {                            // the 36 sums over the wave's 64 lanes, fixed order, through its LDS rows
 #pragma unroll
         for (int i = 0; i < 12; ++i) red[wv][i][lane] = acc[b * 12 + i];
         __builtin_amdgcn_wave_barrier();
@@ -600,11 +633,138 @@ __global__ __launch_bounds__(256, 4) void pg_nodes_rows(pg_args a, int r) {
         }
         v = v + pg_quad_sum_step<1>(v);
         v = v + pg_quad_sum_step<2>(v);
-        if (q < 12 && part == 0) shW[wv][b * 12 + q] = v;
+        if (q < 12 && part == 0) out[b * 12 + q] = v;
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// Nodes somebody merged again (and, twisted proposal, nodes with look-ahead entries), small nodes (S <= 4096), row form:
+// grid (flagged nodes of rank event r: slow_idx[slow0 ...], tiles of 256 sites), thread = site, the node's own matrices in scalar
+// registers, whole 32-byte rows per load, fused multiply-adds.  A rank event has a few dozen such nodes, so the launch is a chain
+// of latencies, not throughput: every load of a thread is issued as early as possible, nothing goes through memory between the
+// adjoint row and the matrix adjoints, and the register count (occupancy 2) does not matter.  The 36 sums of a (node, tile) go
+// to slowpart; pg_node_finish adds the tiles in order.
+__global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int slow0) {
+    __shared__ double shP[PG_PCHUNK][32];
+    __shared__ int shE[PG_PCHUNK];
+    __shared__ int shSib[PG_PCHUNK];
+    __shared__ double shA[PG_PCHUNK];
+    __shared__ pg_rows_lds sh;
+    const int tid = threadIdx.x;
+    const int si = slow0 + blockIdx.x;
+    const size_t node = (size_t)a.slow_idx[si];
+    const bool has_x = (a.slow_flag[node] & 2) != 0;        // pg_twist_xsum left the look-ahead merges' share in the adjoint row
+    const size_t row = (size_t)a.S * 4;
+    const int s = blockIdx.y * 256 + tid;
+    const bool live = s < a.S;
+    const size_t so = (size_t)(live ? s : a.S - 1) * 4;
+    const double* Lrow = pg_row(a, a.child[node * 2]);
+    const double* Rrow = pg_row(a, a.child[node * 2 + 1]);
+    const double* xrow = a.pool + node * row;
+    double* orow = a.adj + node * row;
+    double x[4], L[4], Rv[4], xb[4], x0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x[i] = xrow[so + i]; L[i] = Lrow[so + i]; Rv[i] = Rrow[so + i]; x0[i] = has_x ? orow[so + i] : 0.0; }
+    const double alpha = a.C[node * a.N + (a.N - r - 2)];
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    const int pbeg = a.par_off[node], pend = a.par_off[node + 1];
+    const int hv = a.heavy_first[node];
+    const int np = pend - pbeg;
+    const int nch = hv >= 0 ? (np + PG_HCHUNK - 1) / PG_HCHUNK : 0;
+    if (hv < 0 && np > 0) pg_stage_parents(a, pbeg, np, shP, shE, shSib, shA);
+    const double* Pu = a.Pmat + node * 32;
+    double Pl[16], Pr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { Pl[i] = Pu[i]; Pr[i] = Pu[16 + i]; }
     __syncthreads();
-    if (tid < PG_PART) a.part[node * PG_PART + tid] = ((shW[0][tid] + shW[1][tid]) + shW[2][tid]) + shW[3][tid];
+    double acc[PG_PART];
+#pragma unroll
+    for (int i = 0; i < PG_PART; ++i) acc[i] = 0.0;
+    const double lik = pg_dot4(pi[0], x[0], pi[1], x[1], pi[2], x[2], pi[3], x[3]);
+    const double inv = alpha / lik;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xb[j] = pi[j] * inv + x0[j];
+    if (hv >= 0) {                                           // chunk sums, sixteen rows in flight (added in order)
+        const double* cp = a.cpart + (size_t)hv * row + so;
+        for (int c0 = 0; c0 < nch; c0 += 16) {
+            double q[16][4];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int cc = c0 + u < nch ? c0 + u : nch - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[u][j] = cp[(size_t)cc * row + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (c0 + u < nch) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xb[j] = xb[j] + q[u][j];
+                }
+        }
+    } else {
+        for (int e0 = 0; e0 < np; e0 += 4) {                 // the light node's own parents, four at a time, loads first
+            double xp[4][4], sb[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ee = e0 + u < np ? e0 + u : np - 1;
+                const int enc = __builtin_amdgcn_readfirstlane(shE[ee]);
+                const double* sbp = pg_row(a, shSib[ee]) + so;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { xp[u][j] = 0.0; sb[u][j] = sbp[j]; }
+                if (!(enc & PG_FREE_PARENT)) {
+                    const double* xpp = a.adj + (size_t)(enc >> 1) * row + so;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xp[u][j] = xpp[j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u < np) {
+                    const int e = e0 + u;
+                    const int enc = __builtin_amdgcn_readfirstlane(shE[e]);
+                    const int side = enc & 1;
+                    const double* Psib = shP[e] + (1 - side) * 16;
+                    const double* Pme = shP[e] + side * 16;
+                    double t[4], w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        w[j] = pg_dot4(sb[u][0], Psib[j], sb[u][1], Psib[4 + j], sb[u][2], Psib[8 + j], sb[u][3], Psib[12 + j]);
+                    if (enc & PG_FREE_PARENT) {              // the parent's own term, recomputed: alpha_p pi / (pi . ((me P_me) o (sib P_sib)))
+                        double lik = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            lik = __builtin_fma(pi[j] * w[j], pg_dot4(x[0], Pme[j], x[1], Pme[4 + j], x[2], Pme[8 + j], x[3], Pme[12 + j]), lik);
+                        const double ai = shA[e] / lik;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xp[u][j] = pi[j] * ai;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] = xp[u][j] * w[j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        xb[j] = xb[j] + pg_dot4(t[0], Pme[j * 4], t[1], Pme[j * 4 + 1], t[2], Pme[j * 4 + 2], t[3], Pme[j * 4 + 3]);
+                }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            orow[so + j] = xb[j];
+            acc[32 + j] = x[j] * inv;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double u = pg_dot4(L[0], Pl[j], L[1], Pl[4 + j], L[2], Pl[8 + j], L[3], Pl[12 + j]);
+            const double v = pg_dot4(Rv[0], Pr[j], Rv[1], Pr[4 + j], Rv[2], Pr[8 + j], Rv[3], Pr[12 + j]);
+            const double tl = xb[j] * v, tr = xb[j] * u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i * 4 + j] = L[i] * tl;
+                acc[16 + i * 4 + j] = Rv[i] * tr;
+            }
+        }
+    }
+    pg_rows_reduce(acc, sh, a.slowpart + ((size_t)si * gridDim.y + blockIdx.y) * PG_PART);
 }
 
 // ---- g6: per node: tiles -> Pl_bar, Pr_bar -> branch adjoints and the Q adjoint ----------------------------
@@ -614,8 +774,11 @@ __global__ __launch_bounds__(64) void pg_node_finish(pg_args a) {
     double pb[PG_PART];
 #pragma unroll
     for (int q = 0; q < PG_PART; ++q) pb[q] = 0.0;
-    for (int t = 0; t < a.T; ++t) {
-        const double* p = a.part + (node * a.T + t) * PG_PART;
+    const int sf = a.slowpart ? a.slow_flag[node] : 0;
+    const int nt = sf ? a.TS : a.T;
+    const double* p0 = sf ? a.slowpart + (size_t)(sf >> 2) * a.TS * PG_PART : a.part + node * a.T * PG_PART;
+    for (int t = 0; t < nt; ++t) {
+        const double* p = p0 + (size_t)t * PG_PART;
 #pragma unroll
         for (int q = 0; q < PG_PART; ++q) pb[q] = pb[q] + p[q];
     }
@@ -688,9 +851,21 @@ __global__ __launch_bounds__(256) void pg_reduce(pg_args a) {
         const int q = o - 2 * a.R;                           // 0..3 pi, 4..19 Q
         const int col = q < 4 ? 18 + q : 2 + (q - 4);
         const size_t n = (size_t)a.R * a.K;
-        for (size_t i = tid; i < n; i += 256) acc = acc + a.nodeg[i * PG_NODEG + col];
-        if (a.twist)
-            for (size_t i = tid; i < n; i += 256) acc = acc + a.tw.twnode[i * PG_NODEG + col];
+        // eight loads in flight (clamped index), added in order: one load per trip of the plain loop cost a latency each (33 us)
+        for (int pass = 0; pass < (a.twist ? 2 : 1); ++pass) {
+            const double* src = pass ? a.tw.twnode : a.nodeg;
+            for (size_t i0 = tid; i0 < n; i0 += 8 * 256) {
+                double q8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const size_t i = i0 + (size_t)u * 256 < n ? i0 + (size_t)u * 256 : n - 1;
+                    q8[u] = src[i * PG_NODEG + col];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + (size_t)u * 256 < n) acc = acc + q8[u];
+            }
+        }
         if (q < 4)
             for (int k = tid; k < a.K; k += 256) acc = acc + a.leafterm[k * 4 + q];
     }
@@ -1036,11 +1211,12 @@ __global__ __launch_bounds__(256) void pg_twist_xchunks(pg_args a, int r, int ch
 // grid (nodes of rank event r that have entries, groups of 256 elements of a node row)
 __global__ __launch_bounds__(256) void pg_twist_xsum(pg_args a, int node0, int chunk0) {
     const int ni = node0 + blockIdx.x;
-    const int x = a.tw.xnode_id[ni], c0 = a.tw.xnode_chunk0[ni] - chunk0, nc = a.tw.xnode_nchunks[ni];
+    const int x = a.tw.xnode_id[ni], c0 = a.tw.xnode_chunk0[ni] - chunk0, ncf = a.tw.xnode_nchunks[ni];
+    const int nc = ncf & 0x3fffffff;                         // bit 30: the node's first visit (newest rank event): nothing to add to
     const size_t e = (size_t)blockIdx.y * 256 + threadIdx.x, row = (size_t)a.S * 4;
     if (e >= row) return;
     double* dst = a.adj + (size_t)(x - a.N) * row + e;
-    double v = *dst;
+    double v = (ncf >> 30) ? 0.0 : *dst;
     const double* src = a.tw.tpart + (size_t)c0 * row + e;
     for (int cb = 0; cb < nc; cb += 8) {                     // eight chunk rows in flight, added in order
         double q[8];

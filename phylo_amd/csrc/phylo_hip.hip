@@ -135,7 +135,7 @@ struct phylo_ctx {
     int64_t* d_joff = nullptr;           // [R+1]
     size_t htw_rows = 0;                 // rows the history holds
     std::vector<int64_t> h_joff;
-    bool last_graph_twist = false;
+    bool last_graph_twist = false, last_graph_marks = false;   // marks: the sweep was lazy, d_mark says which nodes were adopted
     int last_M = 1;
     // graph kept for the reverse pass (PHYLO_KEEP_GRAPH; allocated on first use)
     int32_t *d_hroots = nullptr, *d_hcnt = nullptr, *d_pos = nullptr;   // [(R+1)][K][N], [(R+1)][K][N], [R][K][N]
@@ -144,6 +144,7 @@ struct phylo_ctx {
     double *d_leafpi = nullptr, *d_leafterm = nullptr, *d_terms = nullptr, *d_gout = nullptr;
     int32_t *d_ad_off = nullptr, *d_ad_idx = nullptr, *d_par_off = nullptr, *d_par_idx = nullptr;
     int32_t *d_heavy = nullptr, *d_chunk_beg = nullptr, *d_chunk_cnt = nullptr;   // [R K], [<= 2 R K / PG_PCHUNK + 1] x2
+    int32_t *d_slow_flag = nullptr, *d_slow_idx = nullptr;                        // [R K] x2
     bool graph_ready = false, last_graph = false;
     int last_G = 1;
     bool last_final_missing = false;
@@ -261,6 +262,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_leafpi = c->d_leafterm = c->d_terms = c->d_gout = nullptr;
     c->d_ad_off = c->d_ad_idx = c->d_par_off = c->d_par_idx = nullptr;
     c->d_heavy = c->d_chunk_beg = c->d_chunk_cnt = nullptr;
+    c->d_slow_flag = c->d_slow_idx = nullptr;
     if (c->h_csr_p) (void)hipHostFree(c->h_csr_p);
     if (c->h_anc_p) (void)hipHostFree(c->h_anc_p);
     if (c->h_child_p) (void)hipHostFree(c->h_child_p);
@@ -367,7 +369,7 @@ int ensure_graph_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_gout, 2 * R + 20));
     {   // the integer lists of the reverse pass live in ONE slab, uploaded with one copy per step
         const size_t cap = 2 * R * K / 4 + 1;
-        c->h_csr_cap = R * (K + 1) + R * K + (R * K + 1) + 2 * R * K + R * K + 2 * cap;
+        c->h_csr_cap = R * (K + 1) + R * K + (R * K + 1) + 2 * R * K + R * K + 2 * cap + 2 * R * K;
         CHK(dalloc(c, &c->d_ad_off, c->h_csr_cap));
         HIPCHK(c, hipHostMalloc((void**)&c->h_csr_p, c->h_csr_cap * 4));
         HIPCHK(c, hipHostMalloc((void**)&c->h_anc_p, (R > 1 ? (R - 1) * K : 1) * 8));
@@ -379,6 +381,8 @@ int ensure_graph_state(phylo_ctx* c) {
         c->d_heavy = c->d_par_idx + 2 * R * K;
         c->d_chunk_beg = c->d_heavy + R * K;
         c->d_chunk_cnt = c->d_chunk_beg + cap;
+        c->d_slow_flag = c->d_chunk_cnt + cap;
+        c->d_slow_idx = c->d_slow_flag + R * K;
     }
     if (!c->evb0) {
         HIPCHK(c, hipEventCreate(&c->evb0));
@@ -819,7 +823,9 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
             HIPCHK(c, hipMemcpyAsync(c->d_joff, c->h_joff.data(), ((size_t)R + 1) * 8, hipMemcpyHostToDevice, c->stream));
         }
     }
-    const bool lazy_ok = !twist && !graph && !(flags & PHYLO_EAGER_NODES) && !c->env.eager_nodes;
+    // A kept graph stays lazy too when its reverse pass reads no node but the adopted ones (rows form, S <= 4096: pg_nodes_free
+    // recomputes a node's row from its children; everything else that is read was somebody's child, i.e. adopted).
+    const bool lazy_ok = !twist && (!graph || S <= 4096) && !(flags & PHYLO_EAGER_NODES) && !c->env.eager_nodes;
     // marks are plain stores and the extra launch costs less than the dead stores it removes at every size measured.
     // Sharded, the owner's write needs one more (tiny) collective per rank event (sweep_step_a); rehearsed with a
     // one-rank RCCL world (PHYLO_REHEARSE_SHARDED=1) the lazy sweep is 0.145 ms against 0.185 ms for the eager one at
@@ -1325,6 +1331,7 @@ int phylo_sweep_finish(phylo_ctx* c) {
     c->last_lazy = lazy;
     c->last_graph = graph;
     c->last_graph_twist = graph && twist;
+    c->last_graph_marks = graph && c->run.lazy;
     c->last_M = c->run.M;
     c->last_G = c->run.G;
     c->last_final_missing = c->run.final_missing;
@@ -1490,6 +1497,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     g.child = c->d_child; g.pos = c->d_pos; g.roots = c->d_hroots;
     g.ad_off = c->d_ad_off; g.ad_idx = c->d_ad_idx; g.par_off = c->d_par_off; g.par_idx = c->d_par_idx;
     g.heavy_first = c->d_heavy; g.chunk_beg = c->d_chunk_beg; g.chunk_cnt = c->d_chunk_cnt;
+    g.slow_flag = c->d_slow_flag; g.slow_idx = c->d_slow_idx;
     g.om = c->d_om; g.G = c->d_G; g.C = c->d_C; g.part = c->d_part; g.nodeg = c->d_nodeg;
     g.leafpi = c->d_leafpi; g.leafterm = c->d_leafterm; g.terms = c->d_terms; g.out = c->d_gout;
     if (twist) {
@@ -1508,6 +1516,14 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     CHK(launch_check(c, "pg_omega"));
     hipLaunchKernelGGL(pg_leafpi, dim3(N), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_leafpi"));
+    // a lazy sweep left marks: a node nobody adopted has no parents and alpha = omega, known without any list -- nearly all
+    // nodes, done while the host builds the lists
+    const bool early_free = rows_form && !twist && c->last_graph_marks;
+    if (early_free) {
+        g.mark = c->d_mark;
+        hipLaunchKernelGGL(pg_nodes_free, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, c->stream, g, 0);
+        CHK(launch_check(c, "pg_nodes_free"));
+    }
     int tw_launches = 0;
     if (twist) {
         const size_t J0 = (size_t)((N * (N - 1)) / 2) * c->last_M;
@@ -1535,13 +1551,13 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
                 ++tw_launches;
             }
         }
-        HIPCHK(c, hipMemsetAsync(c->d_adj, 0, (size_t)R * K * S * 4 * 8, c->stream));   // pg_twist_xsum accumulates, pg_nodes starts from it
-        tw_launches += 3;
+        tw_launches += 2;
     }
     // ---- integer bookkeeping of the reverse pass: who adopted whom, and which nodes have which parents.  The sweep left the
     //      ancestors and children in pinned host memory (asynchronous copies behind its last launch); the lists are built straight
     //      into the pinned image of the device slab (ad_off | ad_idx | par_off | par_idx | heavy | chunk_beg | chunk_cnt).
     HIPCHK(c, hipEventSynchronize(c->ev_gcopy));
+    const auto host_t0 = std::chrono::steady_clock::now();
     const int64_t* anc = c->h_anc_p;
     const int32_t* child = c->h_child_p;
     const size_t cap = 2 * nn / 4 + 1;
@@ -1552,7 +1568,10 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     int32_t* heavy = par_idx + 2 * nn;
     int32_t* chunk_beg = heavy + nn;
     int32_t* chunk_cnt = chunk_beg + cap;
+    int32_t* slow_flag = chunk_cnt + cap;
+    int32_t* slow_idx = slow_flag + nn;
     memset(ad_off, 0, ((size_t)R * (K + 1) + nn + nn + 1) * 4);      // ad_off, ad_idx, par_off
+    memset(slow_flag, 0, nn * 4);
     std::vector<int32_t>& cur = c->h_cur;
     for (int r = 1; r < R; ++r) {                          // counting sort by ancestor; ties keep ascending k'
         int32_t* off = ad_off + (size_t)r * (K + 1);
@@ -1592,7 +1611,6 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     void* cpart = nullptr;
     CHK(scratch_get(c, 5, max_chunks * (size_t)S * 4 * 8, &cpart));
     g.cpart = (double*)cpart;
-    HIPCHK(c, hipMemcpyAsync(c->d_ad_off, c->h_csr_p, c->h_csr_cap * 4, hipMemcpyHostToDevice, c->stream));
     // twisted proposal: the look-ahead merges of rank event r touch every internal node among the adopted roots.  Entries
     // (adopter, slot) grouped by node (ascending adopter), cut into chunks of PG_XCH; lists for all rank events in one upload.
     std::vector<int32_t> ev_chunk0((size_t)R + 1, 0), ev_node0((size_t)R + 1, 0);
@@ -1661,6 +1679,12 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         ev_chunk0[R] = (int32_t)xc_node.size();
         ev_node0[R] = (int32_t)xn_id.size();
         n_xent = xent.size(); n_xchunks = xc_node.size(); n_xnodes = xn_id.size();
+        // the newest rank event that touches a node is launched first: its pg_twist_xsum starts the node's adjoint row (bit 30)
+        // instead of adding to it, so nothing has to be cleared; such a node goes through pg_nodes_rows (flag bit 1)
+        for (size_t i = n_xnodes; i-- > 0;) {
+            int32_t& f = slow_flag[xn_id[i] - N];
+            if (!(f & 2)) { f |= 2; xn_nc[i] |= 1 << 30; }
+        }
         std::vector<int32_t>& pk = c->h_xlists;
         pk.resize(n_xent + 4 * n_xchunks + 3 * n_xnodes + 1);
         int32_t* w = pk.data();
@@ -1670,6 +1694,36 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         HIPCHK(c, hipMemcpyAsync(d_xlists, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, c->stream));
         CHK(scratch_get(c, 7, tw_max_chunks * (size_t)S * 4 * 8, &d_tpart));
     }
+    // nodes with parents or look-ahead entries, by rank event: pg_nodes_rows; all the others in one launch (pg_nodes_free)
+    std::vector<int32_t> ev_slow0((size_t)R + 1, 0);
+    {
+        int32_t ns = 0;
+        for (int r = 0; r < R; ++r) {
+            ev_slow0[r] = ns;
+            for (int k = 0; k < K; ++k) {
+                const size_t x = (size_t)r * K + k;
+                if (par_off[x + 1] > par_off[x]) slow_flag[x] |= 1;
+                if (slow_flag[x]) {
+                    slow_flag[x] |= ns << 2;
+                    slow_idx[ns++] = (int32_t)x;
+                }
+            }
+        }
+        ev_slow0[R] = ns;
+        if (rows_form) {                                   // parents whose adjoint row is never stored: the gather recomputes it
+            const int32_t np_all = par_off[nn];
+            for (int32_t e = 0; e < np_all; ++e)
+                if (!slow_flag[par_idx[e] >> 1]) par_idx[e] |= PG_FREE_PARENT;
+        }
+        g.TS = cdiv(S, 256);
+        if (rows_form) {
+            void* sp = nullptr;
+            CHK(scratch_get(c, 3, (size_t)(ns ? ns : 1) * g.TS * PG_PART * 8, &sp));
+            g.slowpart = (double*)sp;
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ad_off, c->h_csr_p, c->h_csr_cap * 4, hipMemcpyHostToDevice, c->stream));
+    const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (twist) {
         const int32_t* xl = (const int32_t*)d_xlists;
         g.tw.xent = xl; xl += n_xent;
@@ -1690,6 +1744,12 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     }
     hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_leafterm"));
+    int node_launches = early_free ? 1 : 0;
+    if (rows_form) {                                       // the rest of the nodes nobody merged again (all of them, had the sweep no marks)
+        ++node_launches;
+        hipLaunchKernelGGL(pg_nodes_free, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, c->stream, g, early_free ? 1 : 2);
+        CHK(launch_check(c, "pg_nodes_free"));
+    }
     for (int r = R - 1; r >= 0; --r) {
         if (twist && ev_chunk0[r + 1] > ev_chunk0[r]) {
             hipLaunchKernelGGL(pg_twist_xchunks, dim3(ev_chunk0[r + 1] - ev_chunk0[r], cdiv(S, 256)), dim3(256), 0, c->stream, g, r, (int)ev_chunk0[r]);
@@ -1700,11 +1760,20 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         }
         const int nch = rank_chunk0[r + 1] - rank_chunk0[r];
         if (nch > 0) {
-            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 64), nch), dim3(256), 0, c->stream, g, (int)rank_chunk0[r]);
+            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16), nch), dim3(256), 0, c->stream, g, (int)rank_chunk0[r]);
             CHK(launch_check(c, "pg_parent_chunks"));
+            ++node_launches;
         }
-        if (rows_form) hipLaunchKernelGGL(pg_nodes_rows, dim3(K), dim3(256), 0, c->stream, g, r);
-        else hipLaunchKernelGGL(pg_nodes, dim3(T, K), dim3(256), 0, c->stream, g, r);
+        if (rows_form) {
+            const int nslow = ev_slow0[r + 1] - ev_slow0[r];
+            if (nslow > 0) {
+                hipLaunchKernelGGL(pg_nodes_rows, dim3(nslow, g.TS), dim3(256), 0, c->stream, g, r, (int)ev_slow0[r]);
+                ++node_launches;
+            }
+        } else {
+            hipLaunchKernelGGL(pg_nodes, dim3(T, K), dim3(256), 0, c->stream, g, r);
+            ++node_launches;
+        }
         CHK(launch_check(c, "pg_nodes"));
     }
     hipLaunchKernelGGL(pg_node_finish, dim3(cdiv((long)R * K, 64)), dim3(64), 0, c->stream, g);
@@ -1726,7 +1795,9 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         HIPCHK(c, hipEventElapsedTime(&ms, c->evb0, c->evb1));
         *perf = c->stats;
         perf->sweep_ms = ms;
-        perf->n_launches = 2 * R + 7 + tw_launches;
+        perf->n_launches = R + 7 + node_launches + tw_launches;
+        perf->merge_ms = host_ms;                          // here: host time of the integer lists (the GPU runs the early kernels meanwhile)
+        perf->merge_launches = 0;
     }
     return PHYLO_OK;
 }

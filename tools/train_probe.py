@@ -29,7 +29,7 @@ B = a.sites or S
 v = T.Variables(N, np.log(10.0), a.jcmodel)
 tr = T.Trainer(genome, a.K, v, T.make_optimizer('Adam', 0.01), B, nested=a.nested, M=a.M)
 rng = np.random.default_rng(0)
-fw, bw, wall = [], [], []
+fw, bw, wall, hostms = [], [], [], []
 phases = {}
 if a.phases:                      # wall time of every host call of a step (Trainer.gradients, taken apart)
     orig = {}
@@ -51,10 +51,11 @@ for i in range(a.steps + 3):
     if i >= 3:
         fw.append(tr.last['raw']['forward_ms'])
         bw.append(tr.last['raw']['backward_ms'])
+        hostms.append(tr.last['raw'].get('backward_host_ms', 0.0))
         wall.append((t1 - t0) * 1e3)
 if a.phases:
     print(json.dumps({'host_call_ms': {k: float(np.mean(v)) for k, v in phases.items()}}))
 print(json.dumps({'dataset': a.dataset, 'nested': a.nested, 'M': a.M, 'K': a.K, 'N': N, 'sites': B, 'steps': a.steps,
-                  'forward_ms': float(np.mean(fw)), 'backward_ms': float(np.mean(bw)), 'step_wall_ms': float(np.mean(wall)),
+                  'forward_ms': float(np.mean(fw)), 'backward_ms': float(np.mean(bw)), 'backward_host_ms': float(np.mean(hostms)), 'step_wall_ms': float(np.mean(wall)),
                   'step_wall_ms_min': float(np.min(wall)), 'last_logZ': tr.last['logZ']}))
 tr.close()
