@@ -69,7 +69,8 @@ struct pg_args {
     const int32_t* heavy_first;        // [R K]: first chunk (within its rank event's chunk range) of a heavy node, else -1
     const int32_t *chunk_beg, *chunk_cnt;   // per chunk: first entry of par_idx, number of entries (<= PG_HCHUNK)
     double* cpart;                     // [chunks of one rank event][S][4]
-    const int32_t* slow_flag;          // [R K]: 0: pg_nodes_free; else pg_nodes_rows: (index in slow_idx) << 2 | (bit 0: has parents, bit 1: look-ahead entries)
+    const int32_t* slow_flag;          // [R K]: 0: pg_nodes_free; else pg_nodes_rows: (index in slow_idx) << 3 | (bit 0: has parents, bit 1: look-ahead
+                                       // entries, bit 2: adopted, left out by the early pg_nodes_free)
     const int32_t* slow_idx;           // the flagged nodes, grouped by rank event (rows form)
     const unsigned int* mark;          // [R][K] or NULL: node (r, k) was adopted at rank event r + 1 (the lazy sweep's marks)
     double* slowpart;                  // [flagged nodes][TS][PG_PART] (rows form; else NULL): their partial sums, TS tiles of 256 sites
@@ -77,7 +78,8 @@ struct pg_args {
     double *om, *G;                    // [R][K]
     double* C;                         // [R][K][N]: coefficient of sum_s log(pi . X) of every root slot after rank event r
     double* part;                      // [R][K][T][PG_PART]
-    double* nodeg;                     // [R][K][PG_NODEG]
+    double* nodeg;                     // [R][K][PG_NODEG] (pg_node_finish writes the two branch adjoints only; the rest: fin_part)
+    double* fin_part;                  // [ceil(R K / 64)][20]: Q_bar[16], pi_bar[4] summed over the 64 nodes of a pg_node_finish workgroup
     double* leafpi;                    // [N][4]: sum_s leaf[s][a] / (pi . leaf[s])
     double* leafterm;                  // [K][4]
     double* terms;                     // [R][K][2]
@@ -89,6 +91,14 @@ struct pg_args {
 // inner products use fused multiply-adds explicitly, which halves their instruction count.
 __device__ __forceinline__ double pg_dot4(double a0, double b0, double a1, double b1, double a2, double b2, double a3, double b3) {
     return __builtin_fma(a3, b3, __builtin_fma(a2, b2, __builtin_fma(a1, b1, a0 * b0)));
+}
+// 1 / x for a normal x > 0 (a site likelihood): v_rcp_f64 and two Newton steps -- a quarter of the instructions of the IEEE
+// division and exact to an ulp or two, which is all a pass with a 1e-9 tolerance needs
+__device__ __forceinline__ double pg_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
 }
 __device__ __forceinline__ double pg_wave_sum(double v) {          // fixed butterfly: same result on every lane
 #pragma unroll
@@ -369,7 +379,7 @@ __device__ __forceinline__ double pg_parent_quad(const pg_args& a, size_t soff, 
                 double lik = pj * (u * w);
                 lik = lik + pg_quad_sum_step<1>(lik);
                 lik = lik + pg_quad_sum_step<2>(lik);
-                xp = shA[e] * pj / lik;
+                xp = (shA[e] * pj) * pg_rcp(lik);
             }
             const double t = xp * w;
             const double t0 = pg_quad<0>(t), t1 = pg_quad<1>(t), t2 = pg_quad<2>(t), t3 = pg_quad<3>(t);
@@ -379,10 +389,13 @@ __device__ __forceinline__ double pg_parent_quad(const pg_args& a, size_t soff, 
     return xb;
 }
 
-// grid (groups of 16 sites, chunks of this rank event): cpart[chunk][s] = sum of the chunk's parent contributions.  The chunk's
+// grid (groups of 16 PG_CSTEPS sites, chunks of this rank event): cpart[chunk][s] = sum of the chunk's parent contributions.  The chunk's
 // (up to PG_HCHUNK = 4 PG_PCHUNK) parents are staged at once and each of the four waves gathers its own PG_PCHUNK of them for the
-// same 16 sites, all loads of a wave in flight together; the four partial sums are added in wave order.  (One wave after the
-// other over 64 sites -- the first version -- paid a staging and a gather latency per PG_PCHUNK parents: 19.5 us per launch.)
+// same 16 PG_CSTEPS sites (all sibling rows of the steps in flight together); the four partial sums are added in wave order.
+// (One wave after the other over 64 sites -- the first version -- paid a staging and a gather latency per PG_PCHUNK parents:
+// 19.5 us per launch.  A workgroup's time is staging, ~3 us, + ~2 us of arithmetic per step: one step needs two passes over the
+// chip on an average rank event, four steps make the pass too long: 18.7 / 21.7 us.)
+#define PG_CSTEPS 2
 __global__ __launch_bounds__(256) void pg_parent_chunks(pg_args a, int chunk0) {
     static_assert(PG_HCHUNK == 4 * PG_PCHUNK, "one wave per PG_PCHUNK parents of a chunk");
     __shared__ double shP[PG_HCHUNK][32];
@@ -390,13 +403,20 @@ __global__ __launch_bounds__(256) void pg_parent_chunks(pg_args a, int chunk0) {
     __shared__ int shSib[PG_HCHUNK];
     __shared__ double shA[PG_HCHUNK];
     __shared__ int shMe;
-    __shared__ double shX[4][64];
+    __shared__ double shX[4][PG_CSTEPS][64];
     const int ci = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c0 = a.chunk_beg[chunk0 + ci], cnt = a.chunk_cnt[chunk0 + ci];
-    const int s = blockIdx.x * 16 + (lane >> 2), j = lane & 3;
-    const bool live = s < a.S;
-    const size_t soff = (size_t)(live ? s : a.S - 1) * 4 + j;
+    const int j = lane & 3;
+    const size_t row = (size_t)a.S * 4;
+    size_t soff[PG_CSTEPS];
+    bool live[PG_CSTEPS];
+#pragma unroll
+    for (int it = 0; it < PG_CSTEPS; ++it) {
+        const int s = blockIdx.x * (16 * PG_CSTEPS) + it * 16 + (lane >> 2);
+        live[it] = s < a.S;
+        soff[it] = (size_t)(live[it] ? s : a.S - 1) * 4 + j;
+    }
     for (int i = tid; i < cnt * 32; i += 256) {
         const int e = i >> 5, q = i & 31;
         const int enc = a.par_idx[c0 + e];
@@ -408,14 +428,62 @@ __global__ __launch_bounds__(256) void pg_parent_chunks(pg_args a, int chunk0) {
     }
     __syncthreads();
     const int nc = cnt - wv * PG_PCHUNK < PG_PCHUNK ? cnt - wv * PG_PCHUNK : PG_PCHUNK;
-    double xb = 0.0;
+    double xb[PG_CSTEPS];
+#pragma unroll
+    for (int it = 0; it < PG_CSTEPS; ++it) xb[it] = 0.0;
     if (nc > 0) {
-        const double me = pg_row(a, shMe)[soff];
-        xb = pg_parent_quad(a, soff, j, nc, shP + wv * PG_PCHUNK, shE + wv * PG_PCHUNK, shSib + wv * PG_PCHUNK, shA + wv * PG_PCHUNK, me, 0.0);
+        const int e0 = wv * PG_PCHUNK;
+        const double* merow = pg_row(a, shMe);
+        double me[PG_CSTEPS], sbv[PG_CSTEPS][PG_PCHUNK];
+#pragma unroll
+        for (int it = 0; it < PG_CSTEPS; ++it) me[it] = merow[soff[it]];
+#pragma unroll
+        for (int e = 0; e < PG_PCHUNK; ++e) {
+            const double* sr = pg_row(a, shSib[e0 + (e < nc ? e : nc - 1)]);
+#pragma unroll
+            for (int it = 0; it < PG_CSTEPS; ++it) sbv[it][e] = sr[soff[it]];
+        }
+        const double pj = a.pi[j];
+#pragma unroll
+        for (int e = 0; e < PG_PCHUNK; ++e) {
+            if (e < nc) {                                    // wave-uniform
+                const int enc = __builtin_amdgcn_readfirstlane(shE[e0 + e]);
+                const int side = enc & 1;
+                const double* Psib = shP[e0 + e] + (1 - side) * 16;
+                const double* Pme = shP[e0 + e] + side * 16;
+                const double al = shA[e0 + e];
+#pragma unroll
+                for (int it = 0; it < PG_CSTEPS; ++it) {
+                    const double sb = sbv[it][e];
+                    const double b0 = pg_quad<0>(sb), b1 = pg_quad<1>(sb), b2 = pg_quad<2>(sb), b3 = pg_quad<3>(sb);
+                    const double w = pg_dot4(b0, Psib[j], b1, Psib[4 + j], b2, Psib[8 + j], b3, Psib[12 + j]);
+                    double xp;
+                    if (enc & PG_FREE_PARENT) {              // alpha_p pi / (pi . X_p),  X_p = (me P_me) o (sib P_sib)
+                        const double m = me[it];
+                        const double m0 = pg_quad<0>(m), m1 = pg_quad<1>(m), m2 = pg_quad<2>(m), m3 = pg_quad<3>(m);
+                        const double u = pg_dot4(m0, Pme[j], m1, Pme[4 + j], m2, Pme[8 + j], m3, Pme[12 + j]);
+                        double lik = pj * (u * w);
+                        lik = lik + pg_quad_sum_step<1>(lik);
+                        lik = lik + pg_quad_sum_step<2>(lik);
+                        xp = (al * pj) * pg_rcp(lik);
+                    } else {                                 // a parent with parents of its own (rare in a heavy node's list): its stored row
+                        xp = a.adj[(size_t)(enc >> 1) * row + soff[it]];
+                    }
+                    const double t = xp * w;
+                    const double t0 = pg_quad<0>(t), t1 = pg_quad<1>(t), t2 = pg_quad<2>(t), t3 = pg_quad<3>(t);
+                    xb[it] = xb[it] + pg_dot4(t0, Pme[j * 4], t1, Pme[j * 4 + 1], t2, Pme[j * 4 + 2], t3, Pme[j * 4 + 3]);
+                }
+            }
+        }
     }
-    shX[wv][lane] = xb;
+#pragma unroll
+    for (int it = 0; it < PG_CSTEPS; ++it) shX[wv][it][lane] = xb[it];
     __syncthreads();
-    if (wv == 0 && live) a.cpart[(size_t)ci * a.S * 4 + soff] = ((shX[0][lane] + shX[1][lane]) + shX[2][lane]) + shX[3][lane];
+    if (wv == 0) {
+#pragma unroll
+        for (int it = 0; it < PG_CSTEPS; ++it)
+            if (live[it]) a.cpart[(size_t)ci * row + soff[it]] = ((shX[0][it][lane] + shX[1][it][lane]) + shX[2][it][lane]) + shX[3][it][lane];
+    }
 }
 
 // grid (tiles of PG_NT sites, K)
@@ -554,20 +622,16 @@ __device__ __forceinline__ void pg_rows_reduce(const double (&acc)[PG_PART], pg_
 // and sixteen independent chains per CU hide it where four workgroups did not (132 us per launch at K = 2048, N = 12); the rows
 // of the next 64 sites are loaded while the current ones are used.
 // phase 0 (before the host has built any list; needs the marks of a lazy sweep): the nodes nobody adopted -- no adopters, so
-// alpha = G = omega exactly, and no parents.  phase 1 (after the lists): the adopted nodes without parents.  phase 2: no marks,
-// every node without parents in one launch after the lists.
+// alpha = G = omega exactly, and no parents; the host then flags every adopted node for pg_nodes_rows (a marked node that was not
+// adopted -- phylo_sweep_node marks what it writes -- would be lost: the marks then do not count, phase 1).
+// phase 1 (after the lists, a sweep without marks): every node without parents.
 __global__ __launch_bounds__(256, 3) void pg_nodes_free(pg_args a, int phase) {
     __shared__ double red[4][12][PG_RED_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t node = (size_t)blockIdx.x * 4 + wv;
     if (node >= (size_t)a.R * a.K) return;
-    if (phase == 0) {
-        if (a.mark[node]) return;
-    } else {
-        if (a.slow_flag[node]) return;
-        if (phase == 1 && !a.mark[node]) return;
-    }
+    if (phase == 0 ? a.mark[node] != 0u : a.slow_flag[node] != 0) return;
     const int r = (int)(node / (size_t)a.K);
     const double alpha = phase == 0 ? a.om[node] : a.C[node * a.N + (a.N - r - 2)];
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
@@ -604,7 +668,7 @@ __global__ __launch_bounds__(256, 3) void pg_nodes_free(pg_args a, int phase) {
         }
         const double x0 = u[0] * v[0], x1 = u[1] * v[1], x2 = u[2] * v[2], x3 = u[3] * v[3];
         const double lik = pg_dot4(pi[0], x0, pi[1], x1, pi[2], x2, pi[3], x3);
-        const double inv = alpha / lik;
+        const double inv = alpha * pg_rcp(lik);
         acc[32] = __builtin_fma(x0, inv, acc[32]); acc[33] = __builtin_fma(x1, inv, acc[33]);
         acc[34] = __builtin_fma(x2, inv, acc[34]); acc[35] = __builtin_fma(x3, inv, acc[35]);
 #pragma unroll
@@ -681,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
 #pragma unroll
     for (int i = 0; i < PG_PART; ++i) acc[i] = 0.0;
     const double lik = pg_dot4(pi[0], x[0], pi[1], x[1], pi[2], x[2], pi[3], x[3]);
-    const double inv = alpha / lik;
+    const double inv = alpha * pg_rcp(lik);
 #pragma unroll
     for (int j = 0; j < 4; ++j) xb[j] = pi[j] * inv + x0[j];
     if (hv >= 0) {                                           // chunk sums, sixteen rows in flight (added in order)
@@ -734,7 +798,7 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             lik = __builtin_fma(pi[j] * w[j], pg_dot4(x[0], Pme[j], x[1], Pme[4 + j], x[2], Pme[8 + j], x[3], Pme[12 + j]), lik);
-                        const double ai = shA[e] / lik;
+                        const double ai = shA[e] * pg_rcp(lik);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) xp[u][j] = pi[j] * ai;
                     }
@@ -769,14 +833,15 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
 
 // ---- g6: per node: tiles -> Pl_bar, Pr_bar -> branch adjoints and the Q adjoint ----------------------------
 __global__ __launch_bounds__(64) void pg_node_finish(pg_args a) {
-    const size_t node = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (node >= (size_t)a.R * a.K) return;
+    const size_t node0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = node0 < (size_t)a.R * a.K;
+    const size_t node = valid ? node0 : (size_t)a.R * a.K - 1;
     double pb[PG_PART];
 #pragma unroll
     for (int q = 0; q < PG_PART; ++q) pb[q] = 0.0;
     const int sf = a.slowpart ? a.slow_flag[node] : 0;
     const int nt = sf ? a.TS : a.T;
-    const double* p0 = sf ? a.slowpart + (size_t)(sf >> 2) * a.TS * PG_PART : a.part + node * a.T * PG_PART;
+    const double* p0 = sf ? a.slowpart + (size_t)(sf >> 3) * a.TS * PG_PART : a.part + node * a.T * PG_PART;
     for (int t = 0; t < nt; ++t) {
         const double* p = p0 + (size_t)t * PG_PART;
 #pragma unroll
@@ -799,7 +864,7 @@ __global__ __launch_bounds__(64) void pg_node_finish(pg_args a) {
         double bb = 0.0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) bb = bb + pb[side * 16 + i] * QP[i];
-        out[side] = bb;
+        if (valid) out[side] = bb;
         if (!a.jc) {                                         // <Pbar, L(Qb, E b)> = <b L((Qb)^T, Pbar), E>
             const double b = (side ? a.br : a.bl)[node];
             double At[16], Eb[16], Lf[16];
@@ -812,10 +877,15 @@ __global__ __launch_bounds__(64) void pg_node_finish(pg_args a) {
             for (int i = 0; i < 16; ++i) dQ[i] = dQ[i] + b * Lf[i];
         }
     }
+    // Q_bar and pi_bar are only ever summed over all nodes: the sum over this wave's 64 nodes (fixed butterfly) goes to
+    // fin_part[workgroup][20], which pg_reduce adds up -- not 20 strided columns of R K nodes (28 us)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) out[2 + i] = dQ[i];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) out[18 + q] = pb[32 + q];
+    for (int i = 0; i < 20; ++i) {
+        double v = i < 16 ? dQ[i] : pb[32 + (i - 16)];
+        v = pg_wave_sum(valid ? v : 0.0);
+        if (threadIdx.x == 0) a.fin_part[(size_t)blockIdx.x * 20 + i] = v;
+    }
+    (void)out;
 }
 
 // ---- g7: explicit occurrences of b and lambda in ll_r and in the proposal term; pathwise db/dlambda ---------
@@ -850,10 +920,13 @@ __global__ __launch_bounds__(256) void pg_reduce(pg_args a) {
     } else {
         const int q = o - 2 * a.R;                           // 0..3 pi, 4..19 Q
         const int col = q < 4 ? 18 + q : 2 + (q - 4);
-        const size_t n = (size_t)a.R * a.K;
-        // eight loads in flight (clamped index), added in order: one load per trip of the plain loop cost a latency each (33 us)
-        for (int pass = 0; pass < (a.twist ? 2 : 1); ++pass) {
-            const double* src = pass ? a.tw.twnode : a.nodeg;
+        const int fcol = q < 4 ? 16 + q : q - 4;             // pg_node_finish's per-workgroup sums: Q_bar[16], pi_bar[4]
+        const size_t nf = ((size_t)a.R * a.K + 63) / 64;
+        for (size_t i = tid; i < nf; i += 256) acc = acc + a.fin_part[i * 20 + fcol];
+        if (a.twist) {
+            const size_t n = (size_t)a.R * a.K;
+            // eight loads in flight (clamped index), added in order: one load per trip of a plain loop costs a latency each
+            const double* src = a.tw.twnode;
             for (size_t i0 = tid; i0 < n; i0 += 8 * 256) {
                 double q8[8];
 #pragma unroll

@@ -1456,6 +1456,7 @@ int phylo_sweep_node(phylo_ctx* c, int r, int k, double* out) {
         for (int rho = 0; rho < c->N - 1; ++rho) {       // sharded: a collective (every rank must call phylo_sweep_node)
             hipLaunchKernelGGL(pk_materialize_rank, dim3(c->Kloc), dim3(PK_COLS), 0, c->stream, b, rho);
             CHK(launch_check(c, "pk_materialize_rank"));
+            c->last_graph_marks = false;                   // the marks now cover more than the adopted nodes
             if (c->comm.transport != 0) {
                 double* rows[1] = {c->d_sync};
                 CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
@@ -1582,6 +1583,17 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         int32_t* idx = ad_idx + (size_t)r * K;
         for (int k = 0; k < K; ++k) idx[cur[a[k]]++] = k;
     }
+    // the adopters' lists are all the coefficient chain needs: it runs while the host goes on with the parents' lists
+    const size_t ad_ints = (size_t)R * (K + 1) + nn;
+    HIPCHK(c, hipMemcpyAsync(c->d_ad_off, c->h_csr_p, ad_ints * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(pg_G, dim3(R * K), dim3(64), 0, c->stream, g);
+    CHK(launch_check(c, "pg_G"));
+    for (int r = R - 1; r >= 0; --r) {
+        hipLaunchKernelGGL(pg_coeff, dim3(K, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r);
+        CHK(launch_check(c, "pg_coeff"));
+    }
+    hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
+    CHK(launch_check(c, "pg_leafterm"));
     for (size_t e = 0; e < 2 * nn; ++e)
         if (child[e] >= N) ++par_off[(size_t)(child[e] - N) + 1];
     for (size_t i = 0; i < nn; ++i) par_off[i + 1] += par_off[i];
@@ -1703,8 +1715,10 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
             for (int k = 0; k < K; ++k) {
                 const size_t x = (size_t)r * K + k;
                 if (par_off[x + 1] > par_off[x]) slow_flag[x] |= 1;
+                // the early launch skipped every marked (= adopted) node: those without parents join the few flagged ones
+                if (early_free && r + 1 < R && ad_off[(size_t)(r + 1) * (K + 1) + k + 1] > ad_off[(size_t)(r + 1) * (K + 1) + k]) slow_flag[x] |= 4;
                 if (slow_flag[x]) {
-                    slow_flag[x] |= ns << 2;
+                    slow_flag[x] |= ns << 3;
                     slow_idx[ns++] = (int32_t)x;
                 }
             }
@@ -1716,13 +1730,18 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
                 if (!slow_flag[par_idx[e] >> 1]) par_idx[e] |= PG_FREE_PARENT;
         }
         g.TS = cdiv(S, 256);
+        {
+            void* fp = nullptr;
+            CHK(scratch_get(c, 2, ((nn + 63) / 64) * 20 * 8, &fp));
+            g.fin_part = (double*)fp;
+        }
         if (rows_form) {
             void* sp = nullptr;
             CHK(scratch_get(c, 3, (size_t)(ns ? ns : 1) * g.TS * PG_PART * 8, &sp));
             g.slowpart = (double*)sp;
         }
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_ad_off, c->h_csr_p, c->h_csr_cap * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_ad_off + ad_ints, c->h_csr_p + ad_ints, (c->h_csr_cap - ad_ints) * 4, hipMemcpyHostToDevice, c->stream));
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (twist) {
         const int32_t* xl = (const int32_t*)d_xlists;
@@ -1736,18 +1755,10 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         g.tw.xnode_nchunks = xl;
         g.tw.tpart = (double*)d_tpart;
     }
-    hipLaunchKernelGGL(pg_G, dim3(R * K), dim3(64), 0, c->stream, g);
-    CHK(launch_check(c, "pg_G"));
-    for (int r = R - 1; r >= 0; --r) {
-        hipLaunchKernelGGL(pg_coeff, dim3(K, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r);
-        CHK(launch_check(c, "pg_coeff"));
-    }
-    hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
-    CHK(launch_check(c, "pg_leafterm"));
     int node_launches = early_free ? 1 : 0;
-    if (rows_form) {                                       // the rest of the nodes nobody merged again (all of them, had the sweep no marks)
+    if (rows_form && !early_free) {                        // the sweep left no marks: every node nobody merged again, now
         ++node_launches;
-        hipLaunchKernelGGL(pg_nodes_free, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, c->stream, g, early_free ? 1 : 2);
+        hipLaunchKernelGGL(pg_nodes_free, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, c->stream, g, 1);
         CHK(launch_check(c, "pg_nodes_free"));
     }
     for (int r = R - 1; r >= 0; --r) {
@@ -1760,7 +1771,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         }
         const int nch = rank_chunk0[r + 1] - rank_chunk0[r];
         if (nch > 0) {
-            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16), nch), dim3(256), 0, c->stream, g, (int)rank_chunk0[r]);
+            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), nch), dim3(256), 0, c->stream, g, (int)rank_chunk0[r]);
             CHK(launch_check(c, "pg_parent_chunks"));
             ++node_launches;
         }

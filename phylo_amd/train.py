@@ -123,8 +123,8 @@ class Trainer:
             self._sites = sites.copy()
         self.ctx.set_model(Q, pi, lam_l, lam_r, jc69_closed_form=self.v.jc)
         self.ctx.sweep_async(int(seed), self.flags, self.M)
+        raw = self.ctx.sweep_backward()                     # queued right behind the sweep: no host round trip in between
         out = self.ctx.sweep_fetch(arrays=False)
-        raw = self.ctx.sweep_backward()
         raw['forward_ms'] = out['stats']['sweep_ms']
         return out['logZ'], chain_rules(self.v, Q, pi, lam_l, lam_r, raw), raw
 

@@ -278,6 +278,37 @@ def test_gradient_edge_shapes(N, S, K):
     _check(genome, Q, pi, ll, lr, K=K, seed=6)
 
 
+def test_gradient_same_with_eager_nodes_and_after_sweep_node():
+    """The reverse pass of a lazy kept graph (free nodes before the lists, from the marks), of an eager one (no marks), and of a
+    lazy one whose marks phylo_sweep_node has widened give the same gradient; more than one 256-site tile per adopted node."""
+    rng = np.random.default_rng(41)
+    N, S, K = 7, 300, 96
+    genome = _codes_genome(rng, N, S)
+    Q, pi, ll, lr = _model(rng, N)
+    g, _ = _check(genome, Q, pi, ll, lr, K=K, seed=21)
+    g_eager, _ = _check(genome, Q, pi, ll, lr, K=K, seed=21, flags=_ffi.FLAGS_DEFAULT | _ffi.EAGER_NODES)
+    with _ffi.Context(K, N, S) as ctx:
+        ctx.set_leaves(genome)
+        ctx.set_model(Q, pi, ll, lr)
+        ctx.sweep(21, _ffi.FLAGS_DEFAULT | _ffi.KEEP_GRAPH)
+        ctx.sweep_node(2, 5)                             # writes (and marks) every node the lazy sweep skipped
+        g_node = ctx.sweep_backward()
+    for key in ('d_lam_l', 'd_lam_r', 'd_pi', 'd_Q'):
+        scale = max(np.max(np.abs(g[key])), 1e-300)
+        assert np.max(np.abs(g_eager[key] - g[key])) / scale < 1e-12, key
+        assert np.max(np.abs(g_node[key] - g[key])) / scale < 1e-12, key
+
+
+def test_gradient_flat_weights_many_adopted_nodes():
+    """All-gap rows: every weight equal, so hundreds of distinct ancestors survive each resampling -- many adopted nodes with few
+    parents each (the opposite of the degenerate genealogies of real data)."""
+    rng = np.random.default_rng(43)
+    N, S, K = 8, 70, 256
+    genome = np.ones((N, S, 4))
+    Q, pi, ll, lr = _model(rng, N)
+    _check(genome, Q, pi, ll, lr, K=K, seed=3)
+
+
 def test_gradient_many_taxa():
     """27 taxa (DS1 sites): root tables longer than one slot group of pg_coeff, deep adoption chains."""
     genome = load_dataset('hohna_data_1')['genome'][:, :130]
