@@ -72,6 +72,8 @@ struct pg_args {
     const int32_t* slow_flag;          // [R K]: 0: pg_nodes_free; else pg_nodes_rows: (index in slow_idx) << 3 | (bit 0: has parents, bit 1: look-ahead
                                        // entries, bit 2: adopted, left out by the early pg_nodes_free)
     const int32_t* slow_idx;           // the flagged nodes, grouped by rank event (rows form)
+    const int32_t* adp;                // NULL, or the adopted (r * K + k), grouped by rank event: pg_G / pg_coeff run on these alone --
+                                       // the early pg_nodes_free has written G = C = omega for everybody else
     const unsigned int* mark;          // [R][K] or NULL: node (r, k) was adopted at rank event r + 1 (the lazy sweep's marks)
     double* slowpart;                  // [flagged nodes][TS][PG_PART] (rows form; else NULL): their partial sums, TS tiles of 256 sites
     int TS;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256) void pg_omega(pg_args a) {
 // ---- g2: G_r[k] = d logZ / d ll_r[k] = omega_r[k] - sum of omega_{r+1} over the particles that adopt k -----
 // one wave per (r, k): a surviving particle can have ~K adopters
 __global__ __launch_bounds__(64) void pg_G(pg_args a) {
-    const int t = blockIdx.x, lane = threadIdx.x;
+    const int t = a.adp ? a.adp[blockIdx.x] : (int)blockIdx.x, lane = threadIdx.x;
     const int r = t / a.K, k = t - r * a.K;
     double sub = 0.0;
     if (r + 1 < a.R) {
@@ -215,9 +217,9 @@ __global__ __launch_bounds__(64) void pg_G(pg_args a) {
 
 // ---- g3: root-slot coefficients, one rank event per launch (newest first) ---------------------------------
 // C_r[k][slot] = G_r[k] + sum over adopters k' of C_{r+1}[k'][position of that slot in k''s new table]
-// grid (K, slot groups); 4 waves per workgroup, one slot each.
-__global__ __launch_bounds__(256) void pg_coeff(pg_args a, int r) {
-    const int k = blockIdx.x, lane = threadIdx.x & 63;
+// grid (K -- or the adopted particles of rank event r, adp[adp0 ...] --, slot groups); 4 waves per workgroup, one slot each.
+__global__ __launch_bounds__(256) void pg_coeff(pg_args a, int r, int adp0) {
+    const int k = a.adp ? a.adp[adp0 + blockIdx.x] - r * a.K : (int)blockIdx.x, lane = threadIdx.x & 63;
     const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int n1 = a.N - r - 1;
     if (slot >= n1) return;
@@ -634,6 +636,7 @@ __global__ __launch_bounds__(256, 3) void pg_nodes_free(pg_args a, int phase) {
     if (phase == 0 ? a.mark[node] != 0u : a.slow_flag[node] != 0) return;
     const int r = (int)(node / (size_t)a.K);
     const double alpha = phase == 0 ? a.om[node] : a.C[node * a.N + (a.N - r - 2)];
+
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     const double* Pu = a.Pmat + node * 32;
     double Pl[16], Pr[16];
@@ -699,6 +702,12 @@ __global__ __launch_bounds__(256, 3) void pg_nodes_free(pg_args a, int phase) {
         v = v + pg_quad_sum_step<2>(v);
         if (q < 12 && part == 0) out[b * 12 + q] = v;
         __builtin_amdgcn_wave_barrier();
+    }
+    // nobody adopted (r, k): G = omega, and every root slot's coefficient with it.  (Last: a store ahead of the uniform loads above
+    // turns them into vector loads -- 64 more registers, and the kernel four times slower.)
+    if (phase == 0) {
+        if (lane == 0) a.G[node] = alpha;
+        for (int slot = lane; slot < a.N - r - 1; slot += 64) a.C[node * a.N + slot] = alpha;
     }
 }
 

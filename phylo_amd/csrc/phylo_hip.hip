@@ -144,7 +144,7 @@ struct phylo_ctx {
     double *d_leafpi = nullptr, *d_leafterm = nullptr, *d_terms = nullptr, *d_gout = nullptr;
     int32_t *d_ad_off = nullptr, *d_ad_idx = nullptr, *d_par_off = nullptr, *d_par_idx = nullptr;
     int32_t *d_heavy = nullptr, *d_chunk_beg = nullptr, *d_chunk_cnt = nullptr;   // [R K], [<= 2 R K / PG_PCHUNK + 1] x2
-    int32_t *d_slow_flag = nullptr, *d_slow_idx = nullptr;                        // [R K] x2
+    int32_t *d_slow_flag = nullptr, *d_slow_idx = nullptr, *d_adp = nullptr;      // [R K] x3
     bool graph_ready = false, last_graph = false;
     int last_G = 1;
     bool last_final_missing = false;
@@ -262,7 +262,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_leafpi = c->d_leafterm = c->d_terms = c->d_gout = nullptr;
     c->d_ad_off = c->d_ad_idx = c->d_par_off = c->d_par_idx = nullptr;
     c->d_heavy = c->d_chunk_beg = c->d_chunk_cnt = nullptr;
-    c->d_slow_flag = c->d_slow_idx = nullptr;
+    c->d_slow_flag = c->d_slow_idx = c->d_adp = nullptr;
     if (c->h_csr_p) (void)hipHostFree(c->h_csr_p);
     if (c->h_anc_p) (void)hipHostFree(c->h_anc_p);
     if (c->h_child_p) (void)hipHostFree(c->h_child_p);
@@ -369,7 +369,7 @@ int ensure_graph_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_gout, 2 * R + 20));
     {   // the integer lists of the reverse pass live in ONE slab, uploaded with one copy per step
         const size_t cap = 2 * R * K / 4 + 1;
-        c->h_csr_cap = R * (K + 1) + R * K + (R * K + 1) + 2 * R * K + R * K + 2 * cap + 2 * R * K;
+        c->h_csr_cap = R * (K + 1) + R * K + (R * K + 1) + 2 * R * K + R * K + 2 * cap + 3 * R * K;
         CHK(dalloc(c, &c->d_ad_off, c->h_csr_cap));
         HIPCHK(c, hipHostMalloc((void**)&c->h_csr_p, c->h_csr_cap * 4));
         HIPCHK(c, hipHostMalloc((void**)&c->h_anc_p, (R > 1 ? (R - 1) * K : 1) * 8));
@@ -383,6 +383,7 @@ int ensure_graph_state(phylo_ctx* c) {
         c->d_chunk_cnt = c->d_chunk_beg + cap;
         c->d_slow_flag = c->d_chunk_cnt + cap;
         c->d_slow_idx = c->d_slow_flag + R * K;
+        c->d_adp = c->d_slow_idx + R * K;
     }
     if (!c->evb0) {
         HIPCHK(c, hipEventCreate(&c->evb0));
@@ -1571,58 +1572,54 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     int32_t* chunk_cnt = chunk_beg + cap;
     int32_t* slow_flag = chunk_cnt + cap;
     int32_t* slow_idx = slow_flag + nn;
+    int32_t* adp = slow_idx + nn;
     memset(ad_off, 0, ((size_t)R * (K + 1) + nn + nn + 1) * 4);      // ad_off, ad_idx, par_off
     memset(slow_flag, 0, nn * 4);
     std::vector<int32_t>& cur = c->h_cur;
+    std::vector<int32_t> ev_adp0((size_t)R + 1, 0);        // adopted particles of rank event r: adp[ev_adp0[r] .. ev_adp0[r + 1])
+    int32_t n_adp = 0;
     for (int r = 1; r < R; ++r) {                          // counting sort by ancestor; ties keep ascending k'
         int32_t* off = ad_off + (size_t)r * (K + 1);
         const int64_t* a = anc + (size_t)(r - 1) * K;
         for (int k = 0; k < K; ++k) ++off[a[k] + 1];
-        for (int k = 0; k < K; ++k) off[k + 1] += off[k];
+        ev_adp0[r - 1] = n_adp;
+        for (int k = 0; k < K; ++k) {
+            if (off[k + 1]) adp[n_adp++] = (r - 1) * K + k; // somebody adopts (r - 1, k) at rank event r
+            off[k + 1] += off[k];
+        }
         cur.assign(off, off + K);
         int32_t* idx = ad_idx + (size_t)r * K;
         for (int k = 0; k < K; ++k) idx[cur[a[k]]++] = k;
     }
-    // the adopters' lists are all the coefficient chain needs: it runs while the host goes on with the parents' lists
+    ev_adp0[R - 1] = ev_adp0[R] = n_adp;
+    if (R == 1) ev_adp0[0] = 0;
+    // the adopters' lists are all the coefficient chain needs: it runs while the host goes on with the parents' lists.  When the
+    // early pg_nodes_free has dealt with everybody nobody adopted, the chain runs over the adopted particles alone.
     const size_t ad_ints = (size_t)R * (K + 1) + nn;
     HIPCHK(c, hipMemcpyAsync(c->d_ad_off, c->h_csr_p, ad_ints * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(pg_G, dim3(R * K), dim3(64), 0, c->stream, g);
-    CHK(launch_check(c, "pg_G"));
-    for (int r = R - 1; r >= 0; --r) {
-        hipLaunchKernelGGL(pg_coeff, dim3(K, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r);
-        CHK(launch_check(c, "pg_coeff"));
+    if (early_free) {
+        HIPCHK(c, hipMemcpyAsync(c->d_adp, adp, (size_t)(n_adp ? n_adp : 1) * 4, hipMemcpyHostToDevice, c->stream));
+        g.adp = c->d_adp;
+        if (n_adp > 0) {
+            hipLaunchKernelGGL(pg_G, dim3(n_adp), dim3(64), 0, c->stream, g);
+            CHK(launch_check(c, "pg_G"));
+        }
+        for (int r = R - 2; r >= 0; --r) {
+            const int na = ev_adp0[r + 1] - ev_adp0[r];
+            if (na == 0) continue;
+            hipLaunchKernelGGL(pg_coeff, dim3(na, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r, (int)ev_adp0[r]);
+            CHK(launch_check(c, "pg_coeff"));
+        }
+    } else {
+        hipLaunchKernelGGL(pg_G, dim3(R * K), dim3(64), 0, c->stream, g);
+        CHK(launch_check(c, "pg_G"));
+        for (int r = R - 1; r >= 0; --r) {
+            hipLaunchKernelGGL(pg_coeff, dim3(K, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r, 0);
+            CHK(launch_check(c, "pg_coeff"));
+        }
     }
     hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_leafterm"));
-    for (size_t e = 0; e < 2 * nn; ++e)
-        if (child[e] >= N) ++par_off[(size_t)(child[e] - N) + 1];
-    for (size_t i = 0; i < nn; ++i) par_off[i + 1] += par_off[i];
-    cur.assign(par_off, par_off + nn);
-    for (size_t e = 0; e < 2 * nn; ++e)                    // e = node * 2 + side, ascending
-        if (child[e] >= N) par_idx[cur[child[e] - N]++] = (int32_t)e;
-    // heavy nodes (more than PG_PCHUNK parents): parent list cut into chunks, numbered within the node's rank event
-    std::vector<int32_t> rank_chunk0((size_t)R + 1, 0);
-    size_t max_chunks = 0, n_chunks = 0;
-    for (int r = 0; r < R; ++r) {
-        rank_chunk0[r] = (int32_t)n_chunks;
-        for (int k = 0; k < K; ++k) {
-            const size_t x = (size_t)r * K + k;
-            const int np = par_off[x + 1] - par_off[x];
-            heavy[x] = -1;
-            if (np <= PG_PCHUNK) continue;
-            heavy[x] = (int32_t)(n_chunks - rank_chunk0[r]);
-            for (int b = par_off[x]; b < par_off[x + 1]; b += PG_HCHUNK) {
-                chunk_beg[n_chunks] = b;
-                chunk_cnt[n_chunks] = par_off[x + 1] - b < PG_HCHUNK ? par_off[x + 1] - b : PG_HCHUNK;
-                ++n_chunks;
-            }
-        }
-        if (n_chunks - rank_chunk0[r] > max_chunks) max_chunks = n_chunks - rank_chunk0[r];
-    }
-    rank_chunk0[R] = (int32_t)n_chunks;
-    void* cpart = nullptr;
-    CHK(scratch_get(c, 5, max_chunks * (size_t)S * 4 * 8, &cpart));
-    g.cpart = (double*)cpart;
     // twisted proposal: the look-ahead merges of rank event r touch every internal node among the adopted roots.  Entries
     // (adopter, slot) grouped by node (ascending adopter), cut into chunks of PG_XCH; lists for all rank events in one upload.
     std::vector<int32_t> ev_chunk0((size_t)R + 1, 0), ev_node0((size_t)R + 1, 0);
@@ -1706,29 +1703,79 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         HIPCHK(c, hipMemcpyAsync(d_xlists, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, c->stream));
         CHK(scratch_get(c, 7, tw_max_chunks * (size_t)S * 4 * 8, &d_tpart));
     }
-    // nodes with parents or look-ahead entries, by rank event: pg_nodes_rows; all the others in one launch (pg_nodes_free)
-    std::vector<int32_t> ev_slow0((size_t)R + 1, 0);
+    // ---- parents: entries e = node * 2 + side grouped by child (ascending e).  One pass over the nodes turns the counts into
+    //      offsets and decides everything per node: heavy nodes (more than PG_PCHUNK parents) get their list cut into chunks,
+    //      numbered within the rank event; nodes with parents, look-ahead entries (twisted) or -- after the early pg_nodes_free --
+    //      adopters are flagged and listed by rank event for pg_nodes_rows; all the others: pg_nodes_free.
+    //      (leaf or internal child is a coin toss in the later rank events: no branch on it -- a leaf counts into a dummy)
+    //      (... and 64 dummies in turn: increments of one address are a chain of store-to-load forwards, 5 cycles each)
+    int32_t dummy[64] = {0};
+    for (size_t e = 0; e < 2 * nn; ++e) {
+        const int32_t ch = child[e];
+        int32_t* p = ch >= N ? par_off + (size_t)(ch - N) + 1 : dummy + (e & 63);
+        ++*p;
+    }
+    std::vector<int32_t> rank_chunk0((size_t)R + 1, 0), ev_slow0((size_t)R + 1, 0);
+    size_t max_chunks = 0, n_chunks = 0;
     {
-        int32_t ns = 0;
+        int32_t ns = 0, run = 0;
         for (int r = 0; r < R; ++r) {
+            rank_chunk0[r] = (int32_t)n_chunks;
             ev_slow0[r] = ns;
+            const int32_t* adn = r + 1 < R ? ad_off + (size_t)(r + 1) * (K + 1) : nullptr;
             for (int k = 0; k < K; ++k) {
                 const size_t x = (size_t)r * K + k;
-                if (par_off[x + 1] > par_off[x]) slow_flag[x] |= 1;
+                const int32_t np = par_off[x + 1];           // still the count: the offsets are written behind the read position
+                par_off[x] = run;
+                int32_t f = slow_flag[x];                    // (bit 1 set above: look-ahead entries)
+                if (np) f |= 1;
                 // the early launch skipped every marked (= adopted) node: those without parents join the few flagged ones
-                if (early_free && r + 1 < R && ad_off[(size_t)(r + 1) * (K + 1) + k + 1] > ad_off[(size_t)(r + 1) * (K + 1) + k]) slow_flag[x] |= 4;
-                if (slow_flag[x]) {
-                    slow_flag[x] |= ns << 3;
+                if (early_free && adn && adn[k + 1] > adn[k]) f |= 4;
+                heavy[x] = -1;
+                if (np > PG_PCHUNK) {
+                    heavy[x] = (int32_t)(n_chunks - rank_chunk0[r]);
+                    for (int32_t b = run; b < run + np; b += PG_HCHUNK) {
+                        chunk_beg[n_chunks] = b;
+                        chunk_cnt[n_chunks] = run + np - b < PG_HCHUNK ? run + np - b : PG_HCHUNK;
+                        ++n_chunks;
+                    }
+                }
+                if (f) {
+                    f |= ns << 3;
                     slow_idx[ns++] = (int32_t)x;
                 }
+                slow_flag[x] = f;
+                run += np;
             }
+            if (n_chunks - rank_chunk0[r] > max_chunks) max_chunks = n_chunks - rank_chunk0[r];
         }
+        par_off[nn] = run;
+        rank_chunk0[R] = (int32_t)n_chunks;
         ev_slow0[R] = ns;
-        if (rows_form) {                                   // parents whose adjoint row is never stored: the gather recomputes it
-            const int32_t np_all = par_off[nn];
-            for (int32_t e = 0; e < np_all; ++e)
-                if (!slow_flag[par_idx[e] >> 1]) par_idx[e] |= PG_FREE_PARENT;
+        // a parent that goes through pg_nodes_free never stores its adjoint row: the gather recomputes it (PG_FREE_PARENT)
+        // scatter without a branch on leaf / internal (masks, not ?: -- the compiler made a branch of that, mispredicted every other
+        // time in the later rank events): a leaf child advances one of 64 dummy cursors and writes into the tail of par_idx,
+        // which is never used (the 2 K children of rank event 0 are all leaves)
+        cur.resize(nn + 64);
+        memcpy(cur.data(), par_off, nn * 4);
+        const int32_t free_bit = rows_form ? PG_FREE_PARENT : 0;
+        int32_t* curp = cur.data();
+        const int32_t tail = (int32_t)(2 * nn) - 1;
+        int32_t tmask = 1;                                  // dummy slots: the last min(64, 2 K rounded down to a power of two)
+        while (tmask * 2 <= 2 * K && tmask < 64) tmask *= 2;
+        tmask -= 1;
+        for (size_t e = 0; e < 2 * nn; ++e) {              // e = node * 2 + side, ascending
+            const int32_t ch = child[e];
+            const int32_t in = -(int32_t)(ch >= N);          // all ones: internal child
+            const int32_t lane = (int32_t)(e & 63);
+            const int32_t ci = ((ch - N) & in) | (((int32_t)nn + lane) & ~in);
+            const int32_t pos = curp[ci]++;
+            const int32_t di = (pos & in) | ((tail - (lane & tmask)) & ~in);
+            par_idx[di] = (int32_t)e | (slow_flag[e >> 1] ? 0 : free_bit);
         }
+        void* cpart = nullptr;
+        CHK(scratch_get(c, 5, max_chunks * (size_t)S * 4 * 8, &cpart));
+        g.cpart = (double*)cpart;
         g.TS = cdiv(S, 256);
         {
             void* fp = nullptr;
@@ -1741,7 +1788,8 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
             g.slowpart = (double*)sp;
         }
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_ad_off + ad_ints, c->h_csr_p + ad_ints, (c->h_csr_cap - ad_ints) * 4, hipMemcpyHostToDevice, c->stream));
+    const size_t up2 = (size_t)(adp - ad_off) - ad_ints;  // everything between the adopters' lists and the adopted particles
+    HIPCHK(c, hipMemcpyAsync(c->d_ad_off + ad_ints, c->h_csr_p + ad_ints, up2 * 4, hipMemcpyHostToDevice, c->stream));
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (twist) {
         const int32_t* xl = (const int32_t*)d_xlists;
