@@ -309,6 +309,24 @@ def test_gradient_flat_weights_many_adopted_nodes():
     _check(genome, Q, pi, ll, lr, K=K, seed=3)
 
 
+def test_gradient_more_than_4096_sites():
+    """S > 4096: the reverse pass takes the tile form (pg_nodes, one workgroup per 256 sites of a node, eager nodes) instead of the
+    row form; a heavy node (more than eight parents) so that the parent chunks run too."""
+    rng = np.random.default_rng(47)
+    N, S, K = 5, 4100, 24
+    genome = _codes_genome(rng, N, S)
+    Q, pi, ll, lr = _model(rng, N)
+    _check(genome, Q, pi, ll, lr, K=K, seed=9)
+
+
+def test_twisted_gradient_more_than_4096_sites():
+    rng = np.random.default_rng(48)
+    N, S, K = 4, 4100, 6
+    genome = _codes_genome(rng, N, S)
+    Q, pi, ll, lr = _model(rng, N)
+    _check_twisted(genome, Q, pi, ll, lr, K=K, M=2, seed=4)
+
+
 def test_gradient_many_taxa():
     """27 taxa (DS1 sites): root tables longer than one slot group of pg_coeff, deep adoption chains."""
     genome = load_dataset('hohna_data_1')['genome'][:, :130]
