@@ -189,7 +189,9 @@ int phylo_sweep_node(phylo_ctx* ctx, int r, int k, double* out_Sx4);
  * (PHYLO_TWISTING | PHYLO_KEEP_GRAPH) that includes the look-ahead potentials of every (pair, sub-sample), whose normalised
  * value of the chosen one enters the weight (vncsmc.py:399-401, 491; no stop_gradient there).  With jc69_closed_form the Q and pi
  * outputs are still produced (the reference holds them constant; the host ignores them).
- * perf (may be NULL): sweep_ms = device time of the reverse pass. */
+ * May be called right after phylo_sweep_async (before the fetch): it is then queued behind the sweep without a host round trip.
+ * perf (may be NULL): sweep_ms = device time of the reverse pass, host step included; merge_ms = that host step (building the
+ * integer lists of adopters and parents) alone; n_launches. */
 int phylo_sweep_backward(phylo_ctx* ctx, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q,
                          phylo_stats* perf);
 
