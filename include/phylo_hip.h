@@ -56,7 +56,9 @@ enum {
                                           either (phylo_sweep_node writes them on demand) unless this flag is set */
     PHYLO_KEEP_GRAPH = 1u << 4,        /* keep what phylo_sweep_backward needs (root-table history of every rank
                                           event, every node; with PHYLO_TWISTING also every sub-sample's branch lengths,
-                                          transition matrices and potential); one GPU; implies PHYLO_EAGER_NODES */
+                                          transition matrices and potential); one GPU.  Nodes are stored eagerly with
+                                          PHYLO_TWISTING or more than 4096 sites; otherwise they stay lazy (the reverse pass then
+                                          reads no node but the adopted ones) */
     PHYLO_ONE_LAUNCH = 1u << 5,        /* run the whole sweep as ONE launch of resident workgroups (phylo_persist.h) where that
                                           form applies (phylo_sweep_async / phylo_sweep_batch_async on one GPU, plain proposal,
                                           N <= 32, small nodes) instead of launches per rank event (scan, bookkeeping,
@@ -68,7 +70,8 @@ enum {
 typedef struct phylo_stats {
     double sweep_ms;        /* device time of the whole sweep (hipEvents on the ctx stream)            */
     double merge_ms;        /* sum of the launch durations of the rank events' dominant kernel (only with PHYLO_TIME_KERNELS):
-                               the merge, or pk_twist_potentials for a twisted sweep                       */
+                               the merge, or pk_twist_potentials for a twisted sweep.  From phylo_sweep_backward: the
+                               host time spent building the integer lists                                  */
     int32_t merge_launches; /* number of launches in that sum                                          */
     int32_t n_launches;     /* kernel launches in the sweep                                            */
     double units;           /* particle-site-likelihoods computed by this rank: K_local * S * (N-1)    */
