@@ -152,12 +152,13 @@ struct phylo_ctx {
     // host copies of the kept graph's integer records, in pinned memory: copied asynchronously when the sweep ends, so that the
     // reverse pass finds them on the host without a synchronous copy; and the pinned staging area of its packed integer lists
     int64_t* h_anc_p = nullptr;          // [(R-1)][K]
+    double* h_model_p = nullptr;         // pinned image of the model upload (phylo_set_model)
     int32_t *h_child_p = nullptr, *h_rad_p = nullptr, *h_csr_p = nullptr;   // [R][K][2], [R][K][N] (twisted), the d_ad_off slab
     size_t h_csr_cap = 0;                // int32 elements
     hipEvent_t ev_gcopy = nullptr;
     std::vector<int32_t> h_cur;          // scratch of the counting sorts
     std::vector<int32_t> h_xlists;       // ... of its twisted part
-    hipEvent_t evb0 = nullptr, evb1 = nullptr;
+    hipEvent_t evb0 = nullptr, evb1 = nullptr, ev_model = nullptr;
     phylo_stats stats{};
     sweep_run run;
     int n_merge_events = 0;
@@ -500,6 +501,8 @@ int phylo_destroy(phylo_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->evb0) (void)hipEventDestroy(c->evb0);
     if (c->evb1) (void)hipEventDestroy(c->evb1);
+    if (c->ev_model) (void)hipEventDestroy(c->ev_model);
+    if (c->h_model_p) (void)hipHostFree(c->h_model_p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PHYLO_OK;
@@ -547,16 +550,27 @@ int phylo_set_model(phylo_ctx* c, const double* Q16, const double* pi4, const do
     c->h_lam_l.assign(lam_l, lam_l + R);
     c->h_lam_r.assign(lam_r, lam_r + R);
     c->jc = jc69_closed_form ? 1 : 0;
-    std::vector<double> pack(20 + 2 * (size_t)c->N, 0.0);              // one upload for the 42 numbers
-    memcpy(pack.data(), Q16, 16 * 8);
-    memcpy(pack.data() + 16, pi4, 4 * 8);
-    memcpy(pack.data() + 20, lam_l, (size_t)R * 8);
-    memcpy(pack.data() + 20 + c->N, lam_r, (size_t)R * 8);
-    HIPCHK(c, hipMemcpyAsync(c->d_Q, pack.data(), pack.size() * 8, hipMemcpyHostToDevice, c->stream));
+    // one upload for the 42 numbers, from a pinned image that outlives the call: everything that uses the model is ordered
+    // behind it on the context's stream, so the call does not wait (a training step sets a new model every time).  Only a
+    // previous upload still in flight has to be over before the image is overwritten.
+    const size_t npack = 20 + 2 * (size_t)c->N;
+    if (!c->h_model_p) {
+        HIPCHK(c, hipHostMalloc((void**)&c->h_model_p, npack * 8));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_model, hipEventDisableTiming));
+    } else {
+        HIPCHK(c, hipEventSynchronize(c->ev_model));
+    }
+    double* pack = c->h_model_p;
+    memset(pack, 0, npack * 8);
+    memcpy(pack, Q16, 16 * 8);
+    memcpy(pack + 16, pi4, 4 * 8);
+    memcpy(pack + 20, lam_l, (size_t)R * 8);
+    memcpy(pack + 20 + c->N, lam_r, (size_t)R * 8);
+    HIPCHK(c, hipMemcpyAsync(c->d_Q, pack, npack * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_model, c->stream));
     c->have_model = true;
     c->last_graph = c->last_graph_twist = false;           // a kept graph belongs to the model it was swept with
     CHK(refresh_leaf_ll(c));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return PHYLO_OK;
 }
 
