@@ -81,7 +81,7 @@ struct pg_args {
     double* C;                         // [R][K][N]: coefficient of sum_s log(pi . X) of every root slot after rank event r
     double* part;                      // [R][K][T][PG_PART]
     double* nodeg;                     // [R][K][PG_NODEG] (pg_node_finish writes the two branch adjoints only; the rest: fin_part)
-    double* fin_part;                  // [ceil(R K / 64)][20]: Q_bar[16], pi_bar[4] summed over the 64 nodes of a pg_node_finish workgroup
+    double* fin_part;                  // [ceil(R K / 32)][20]: Q_bar[16], pi_bar[4] summed over the 32 nodes of a pg_node_finish workgroup
     double* leafpi;                    // [N][4]: sum_s leaf[s][a] / (pi . leaf[s])
     double* leafterm;                  // [K][4]
     double* terms;                     // [R][K][2]
@@ -842,59 +842,58 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
 
 // ---- g6: per node: tiles -> Pl_bar, Pr_bar -> branch adjoints and the Q adjoint ----------------------------
 __global__ __launch_bounds__(64) void pg_node_finish(pg_args a) {
-    const size_t node0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one lane per (node, side): the two Frechet series of a node are ~5 k dependent instructions each and the launch lasts as long
+    // as one lane does (a single lane per node: 36 us); the wave's 32 nodes, grid ceil(R K / 32)
+    const int side = threadIdx.x & 1;
+    const size_t node0 = (size_t)blockIdx.x * 32 + (threadIdx.x >> 1);
     const bool valid = node0 < (size_t)a.R * a.K;
     const size_t node = valid ? node0 : (size_t)a.R * a.K - 1;
-    double pb[PG_PART];
+    double pb[16], pib[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int q = 0; q < PG_PART; ++q) pb[q] = 0.0;
+    for (int q = 0; q < 16; ++q) pb[q] = 0.0;
     const int sf = a.slowpart ? a.slow_flag[node] : 0;
     const int nt = sf ? a.TS : a.T;
     const double* p0 = sf ? a.slowpart + (size_t)(sf >> 3) * a.TS * PG_PART : a.part + node * a.T * PG_PART;
     for (int t = 0; t < nt; ++t) {
         const double* p = p0 + (size_t)t * PG_PART;
 #pragma unroll
-        for (int q = 0; q < PG_PART; ++q) pb[q] = pb[q] + p[q];
+        for (int q = 0; q < 16; ++q) pb[q] = pb[q] + p[side * 16 + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pib[q] = pib[q] + p[32 + q];
     }
-    double Q[16], QP[16];
+    double Q[16], QP[16], Pm[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) Q[i] = a.Q[i];
-    double* out = a.nodeg + node * PG_NODEG;
+    const double* P = a.Pmat + node * 32 + side * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Pm[i] = P[i];
+    pm_mm4(Q, Pm, QP);                                       // dP/db = Q P
+    double bb = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bb = bb + pb[i] * QP[i];
+    if (valid) a.nodeg[node * PG_NODEG + side] = bb;
     double dQ[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) dQ[i] = 0.0;
-#pragma unroll 1
-    for (int side = 0; side < 2; ++side) {
-        const double* P = a.Pmat + node * 32 + side * 16;
-        double Pm[16];
+    if (!a.jc) {                                             // <Pbar, L(Qb, E b)> = <b L((Qb)^T, Pbar), E>
+        const double b = (side ? a.br : a.bl)[node];
+        double At[16], Lf[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) Pm[i] = P[i];
-        pm_mm4(Q, Pm, QP);                                   // dP/db = Q P
-        double bb = 0.0;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) bb = bb + pb[side * 16 + i] * QP[i];
-        if (valid) out[side] = bb;
-        if (!a.jc) {                                         // <Pbar, L(Qb, E b)> = <b L((Qb)^T, Pbar), E>
-            const double b = (side ? a.br : a.bl)[node];
-            double At[16], Eb[16], Lf[16];
+            for (int j = 0; j < 4; ++j) At[i * 4 + j] = Q[j * 4 + i] * b;
+        pg_expm4_frechet(At, pb, Lf);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { At[i * 4 + j] = Q[j * 4 + i] * b; Eb[i * 4 + j] = pb[side * 16 + i * 4 + j]; }
-            pg_expm4_frechet(At, Eb, Lf);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dQ[i] = dQ[i] + b * Lf[i];
-        }
+        for (int i = 0; i < 16; ++i) dQ[i] = b * Lf[i];
     }
-    // Q_bar and pi_bar are only ever summed over all nodes: the sum over this wave's 64 nodes (fixed butterfly) goes to
-    // fin_part[workgroup][20], which pg_reduce adds up -- not 20 strided columns of R K nodes (28 us)
+    // Q_bar and pi_bar are only ever summed over all nodes: the sum over this wave's 32 nodes (left side + right side first, then a
+    // fixed butterfly) goes to fin_part[workgroup][20], which pg_reduce adds up -- not 20 strided columns of R K nodes (28 us)
 #pragma unroll
     for (int i = 0; i < 20; ++i) {
-        double v = i < 16 ? dQ[i] : pb[32 + (i - 16)];
+        double v = i < 16 ? dQ[i] : (side == 0 ? pib[i - 16] : 0.0);
         v = pg_wave_sum(valid ? v : 0.0);
         if (threadIdx.x == 0) a.fin_part[(size_t)blockIdx.x * 20 + i] = v;
     }
-    (void)out;
 }
 
 // ---- g7: explicit occurrences of b and lambda in ll_r and in the proposal term; pathwise db/dlambda ---------
@@ -930,7 +929,7 @@ __global__ __launch_bounds__(256) void pg_reduce(pg_args a) {
         const int q = o - 2 * a.R;                           // 0..3 pi, 4..19 Q
         const int col = q < 4 ? 18 + q : 2 + (q - 4);
         const int fcol = q < 4 ? 16 + q : q - 4;             // pg_node_finish's per-workgroup sums: Q_bar[16], pi_bar[4]
-        const size_t nf = ((size_t)a.R * a.K + 63) / 64;
+        const size_t nf = ((size_t)a.R * a.K + 31) / 32;
         for (size_t i = tid; i < nf; i += 256) acc = acc + a.fin_part[i * 20 + fcol];
         if (a.twist) {
             const size_t n = (size_t)a.R * a.K;

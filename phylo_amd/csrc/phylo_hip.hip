@@ -1592,18 +1592,36 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     std::vector<int32_t>& cur = c->h_cur;
     std::vector<int32_t> ev_adp0((size_t)R + 1, 0);        // adopted particles of rank event r: adp[ev_adp0[r] .. ev_adp0[r + 1])
     int32_t n_adp = 0;
-    for (int r = 1; r < R; ++r) {                          // counting sort by ancestor; ties keep ascending k'
+    // counting sort by ancestor; ties keep ascending k'.  A few ancestors take nearly all the draws, so counters and cursors
+    // are chains of store-to-load forwards on one address: the particles are taken as four contiguous quarters with a counter
+    // row each (four independent chains), whose prefix sums give every quarter its own cursor into an ancestor's list.
+    const int Kq = K / 4;
+    cur.assign((size_t)4 * K, 0);
+    for (int r = 1; r < R; ++r) {
         int32_t* off = ad_off + (size_t)r * (K + 1);
         const int64_t* a = anc + (size_t)(r - 1) * K;
-        for (int k = 0; k < K; ++k) ++off[a[k] + 1];
-        ev_adp0[r - 1] = n_adp;
-        for (int k = 0; k < K; ++k) {
-            if (off[k + 1]) adp[n_adp++] = (r - 1) * K + k; // somebody adopts (r - 1, k) at rank event r
-            off[k + 1] += off[k];
-        }
-        cur.assign(off, off + K);
         int32_t* idx = ad_idx + (size_t)r * K;
-        for (int k = 0; k < K; ++k) idx[cur[a[k]]++] = k;
+        int32_t *c0 = cur.data(), *c1 = c0 + K, *c2 = c1 + K, *c3 = c2 + K;
+        if (r > 1) memset(c0, 0, (size_t)4 * K * 4);
+        for (int k = 0; k < Kq; ++k) {
+            ++c0[a[k]]; ++c1[a[k + Kq]]; ++c2[a[k + 2 * Kq]]; ++c3[a[k + 3 * Kq]];
+        }
+        for (int k = 4 * Kq; k < K; ++k) ++c3[a[k]];       // (the last quarter takes the remainder)
+        ev_adp0[r - 1] = n_adp;
+        int32_t run = 0;
+        for (int x = 0; x < K; ++x) {
+            const int32_t t0 = c0[x], t1 = c1[x], t2 = c2[x], t3 = c3[x];
+            off[x] = run;
+            c0[x] = run; c1[x] = run + t0; c2[x] = run + t0 + t1; c3[x] = run + t0 + t1 + t2;
+            const int32_t tot = (t0 + t1) + (t2 + t3);
+            if (tot) adp[n_adp++] = (r - 1) * K + x;        // somebody adopts (r - 1, x) at rank event r
+            run += tot;
+        }
+        off[K] = run;
+        for (int k = 0; k < Kq; ++k) {
+            idx[c0[a[k]]++] = k; idx[c1[a[k + Kq]]++] = k + Kq; idx[c2[a[k + 2 * Kq]]++] = k + 2 * Kq; idx[c3[a[k + 3 * Kq]]++] = k + 3 * Kq;
+        }
+        for (int k = 4 * Kq; k < K; ++k) idx[c3[a[k]]++] = k;
     }
     ev_adp0[R - 1] = ev_adp0[R] = n_adp;
     if (R == 1) ev_adp0[0] = 0;
@@ -1793,7 +1811,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         g.TS = cdiv(S, 256);
         {
             void* fp = nullptr;
-            CHK(scratch_get(c, 2, ((nn + 63) / 64) * 20 * 8, &fp));
+            CHK(scratch_get(c, 2, ((nn + 31) / 32) * 20 * 8, &fp));
             g.fin_part = (double*)fp;
         }
         if (rows_form) {
@@ -1849,7 +1867,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         }
         CHK(launch_check(c, "pg_nodes"));
     }
-    hipLaunchKernelGGL(pg_node_finish, dim3(cdiv((long)R * K, 64)), dim3(64), 0, c->stream, g);
+    hipLaunchKernelGGL(pg_node_finish, dim3(cdiv((long)R * K, 32)), dim3(64), 0, c->stream, g);
     CHK(launch_check(c, "pg_node_finish"));
     hipLaunchKernelGGL(pg_scalars, dim3(nrk), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_scalars"));
