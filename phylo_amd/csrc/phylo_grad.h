@@ -179,6 +179,22 @@ __device__ inline void pg_expm4_frechet(const double* A0, const double* E0, doub
     for (int i = 0; i < 16; ++i) Lout[i] = SD[i];
 }
 
+// ---- copies between device memory and PINNED host memory by a kernel (the host pointer is device-visible): the integer lists of
+// the reverse pass go down (ancestors, children) and up (adopters, parents) once per training step, a few hundred KB each, in
+// the middle of a chain of dependent launches -- where a copy through the DMA engine costs 30-40 us of start-up, a launch 5.
+// Up to three ranges per launch; 4-byte words, grid-stride.
+struct pg_copy3 {
+    const uint32_t* src[3];
+    uint32_t* dst[3];
+    size_t n[3];                                            // words
+};
+__global__ __launch_bounds__(256) void pg_copy_words(pg_copy3 a) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[q]; i += stride) a.dst[q][i] = a.src[q][i];
+}
+
 // ---- g1: omega = softmax_k(log w_r) ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void pg_omega(pg_args a) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -153,6 +153,7 @@ struct phylo_ctx {
     // reverse pass finds them on the host without a synchronous copy; and the pinned staging area of its packed integer lists
     int64_t* h_anc_p = nullptr;          // [(R-1)][K]
     double* h_model_p = nullptr;         // pinned image of the model upload (phylo_set_model)
+    uint32_t *hd_csr = nullptr, *hd_anc = nullptr, *hd_child = nullptr, *hd_rad = nullptr;   // device views of h_csr_p, h_anc_p, h_child_p, h_rad_p
     int32_t *h_child_p = nullptr, *h_rad_p = nullptr, *h_csr_p = nullptr;   // [R][K][2], [R][K][N] (twisted), the d_ad_off slab
     size_t h_csr_cap = 0;                // int32 elements
     hipEvent_t ev_gcopy = nullptr;
@@ -375,6 +376,10 @@ int ensure_graph_state(phylo_ctx* c) {
         HIPCHK(c, hipHostMalloc((void**)&c->h_csr_p, c->h_csr_cap * 4));
         HIPCHK(c, hipHostMalloc((void**)&c->h_anc_p, (R > 1 ? (R - 1) * K : 1) * 8));
         HIPCHK(c, hipHostMalloc((void**)&c->h_child_p, R * K * 2 * 4));
+        // device views of the pinned buffers (pg_copy_words reads / writes them from kernels)
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_csr, c->h_csr_p, 0));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_anc, c->h_anc_p, 0));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_child, c->h_child_p, 0));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_gcopy, hipEventDisableTiming));
         c->d_ad_idx = c->d_ad_off + R * (K + 1);
         c->d_par_off = c->d_ad_idx + R * K;
@@ -834,6 +839,7 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
                 CHK(dalloc(c, &c->d_twnode, (size_t)R * K * PG_NODEG));
                 CHK(dalloc(c, &c->d_joff, (size_t)R + 1));
                 HIPCHK(c, hipHostMalloc((void**)&c->h_rad_p, (size_t)R * K * N * 4));
+                HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_rad, c->h_rad_p, 0));
             }
             HIPCHK(c, hipMemcpyAsync(c->d_joff, c->h_joff.data(), ((size_t)R + 1) * 8, hipMemcpyHostToDevice, c->stream));
         }
@@ -1336,9 +1342,13 @@ int phylo_sweep_finish(phylo_ctx* c) {
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     if (graph) {                                           // the reverse pass builds its lists from these on the host
-        if (R > 1) HIPCHK(c, hipMemcpyAsync(c->h_anc_p, c->d_anc, (size_t)(R - 1) * c->K * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_child_p, c->d_child, (size_t)R * c->K * 2 * 4, hipMemcpyDeviceToHost, c->stream));
-        if (twist) HIPCHK(c, hipMemcpyAsync(c->h_rad_p, c->d_hroots_ad, (size_t)R * c->K * N * 4, hipMemcpyDeviceToHost, c->stream));
+        pg_copy3 cp{};                                     // (by a kernel into the pinned buffers: pg_copy_words says why)
+        cp.src[0] = (const uint32_t*)c->d_anc; cp.dst[0] = c->hd_anc; cp.n[0] = R > 1 ? (size_t)(R - 1) * c->K * 2 : 0;
+        cp.src[1] = (const uint32_t*)c->d_child; cp.dst[1] = c->hd_child; cp.n[1] = (size_t)R * c->K * 2;
+        if (twist) { cp.src[2] = (const uint32_t*)c->d_hroots_ad; cp.dst[2] = c->hd_rad; cp.n[2] = (size_t)R * c->K * N; }
+        const size_t words = cp.n[0] + cp.n[1] + cp.n[2];
+        hipLaunchKernelGGL(pg_copy_words, dim3((unsigned)(words / 1024 < 1 ? 1 : (words / 1024 > 1024 ? 1024 : words / 1024))), dim3(256), 0, c->stream, cp);
+        CHK(launch_check(c, "pg_copy_words"));
         HIPCHK(c, hipEventRecord(c->ev_gcopy, c->stream));
     }
     c->swept = true;
@@ -1820,8 +1830,16 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
             g.slowpart = (double*)sp;
         }
     }
-    const size_t up2 = (size_t)(adp - ad_off) - ad_ints;  // everything between the adopters' lists and the adopted particles
-    HIPCHK(c, hipMemcpyAsync(c->d_ad_off + ad_ints, c->h_csr_p + ad_ints, up2 * 4, hipMemcpyHostToDevice, c->stream));
+    {   // what was used of everything between the adopters' lists and the adopted particles, by a kernel (pg_copy_words)
+        pg_copy3 cp{};
+        const size_t o0 = (size_t)(par_off - ad_off), o1 = (size_t)(heavy - ad_off), o2 = (size_t)(slow_flag - ad_off);
+        cp.src[0] = c->hd_csr + o0; cp.dst[0] = (uint32_t*)(c->d_ad_off + o0); cp.n[0] = nn + 1 + (size_t)par_off[nn];   // par_off | par_idx
+        cp.src[1] = c->hd_csr + o1; cp.dst[1] = (uint32_t*)(c->d_ad_off + o1); cp.n[1] = nn + cap + n_chunks;            // heavy | chunk_beg | chunk_cnt
+        cp.src[2] = c->hd_csr + o2; cp.dst[2] = (uint32_t*)(c->d_ad_off + o2); cp.n[2] = nn + (size_t)ev_slow0[R];       // slow_flag | slow_idx
+        const size_t words = cp.n[0] + cp.n[1] + cp.n[2];
+        hipLaunchKernelGGL(pg_copy_words, dim3((unsigned)(words / 1024 < 1 ? 1 : (words / 1024 > 1024 ? 1024 : words / 1024))), dim3(256), 0, c->stream, cp);
+        CHK(launch_check(c, "pg_copy_words"));
+    }
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (twist) {
         const int32_t* xl = (const int32_t*)d_xlists;
