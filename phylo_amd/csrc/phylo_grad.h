@@ -182,16 +182,17 @@ __device__ inline void pg_expm4_frechet(const double* A0, const double* E0, doub
 // ---- copies between device memory and PINNED host memory by a kernel (the host pointer is device-visible): the integer lists of
 // the reverse pass go down (ancestors, children) and up (adopters, parents) once per training step, a few hundred KB each, in
 // the middle of a chain of dependent launches -- where a copy through the DMA engine costs 30-40 us of start-up, a launch 5.
-// Up to three ranges per launch; 4-byte words, grid-stride.
+// Up to PG_COPY_N ranges per launch; 4-byte words, grid-stride.
+#define PG_COPY_N 5
 struct pg_copy3 {
-    const uint32_t* src[3];
-    uint32_t* dst[3];
-    size_t n[3];                                            // words
+    const uint32_t* src[PG_COPY_N];
+    uint32_t* dst[PG_COPY_N];
+    size_t n[PG_COPY_N];                                    // words
 };
 __global__ __launch_bounds__(256) void pg_copy_words(pg_copy3 a) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < PG_COPY_N; ++q)
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[q]; i += stride) a.dst[q][i] = a.src[q][i];
 }
 
@@ -643,15 +644,27 @@ __device__ __forceinline__ void pg_rows_reduce(const double (&acc)[PG_PART], pg_
 // alpha = G = omega exactly, and no parents; the host then flags every adopted node for pg_nodes_rows (a marked node that was not
 // adopted -- phylo_sweep_node marks what it writes -- would be lost: the marks then do not count, phase 1).
 // phase 1 (after the lists, a sweep without marks): every node without parents.
+// G = C = omega for every (r, k) nobody adopted (see pg_nodes_free, phase 0): as a launch of its own, thread per (r, k), when the
+// long pg_nodes_free runs in the background on another stream and the coefficient chain must not wait for it (phase 3 there).
+__global__ __launch_bounds__(256) void pg_fill_free(pg_args a) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)a.R * a.K || a.mark[t]) return;
+    const int r = (int)(t / (size_t)a.K);
+    const double om = a.om[t];
+    a.G[t] = om;
+    for (int slot = 0; slot < a.N - r - 1; ++slot) a.C[t * a.N + slot] = om;
+}
+
 __global__ __launch_bounds__(256, 3) void pg_nodes_free(pg_args a, int phase) {
     __shared__ double red[4][12][PG_RED_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t node = (size_t)blockIdx.x * 4 + wv;
     if (node >= (size_t)a.R * a.K) return;
-    if (phase == 0 ? a.mark[node] != 0u : a.slow_flag[node] != 0) return;
+    const bool by_marks = phase == 0 || phase == 3;
+    if (by_marks ? a.mark[node] != 0u : a.slow_flag[node] != 0) return;
     const int r = (int)(node / (size_t)a.K);
-    const double alpha = phase == 0 ? a.om[node] : a.C[node * a.N + (a.N - r - 2)];
+    const double alpha = by_marks ? a.om[node] : a.C[node * a.N + (a.N - r - 2)];
 
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     const double* Pu = a.Pmat + node * 32;

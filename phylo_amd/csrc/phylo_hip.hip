@@ -47,7 +47,7 @@ struct sweep_run {                       // a sweep being issued rank event by r
 struct env_switches {
     bool eager_nodes = false, rehearse_sharded = false, replicated_book = false, fuse_scan = false,
          book_one_per_wave = false, merge_pair_form = false, no_leaf_codes = false, one_launch = false,
-         persist_stamps = false, separate_materialise = false;
+         persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, no_spin_wait = false;
     int persist_wgs = 0;                 // PHYLO_PERSIST_WGS: resident workgroups of the one-launch sweep (0 = default)
     int persist_nt = 256;                // PHYLO_PERSIST_NT: threads per workgroup of the one-launch sweep (256 or 512)
     void read() {
@@ -61,6 +61,9 @@ struct env_switches {
         one_launch = getenv("PHYLO_ONE_LAUNCH") != nullptr;
         persist_stamps = getenv("PHYLO_PERSIST_STAMPS") != nullptr;
         separate_materialise = getenv("PHYLO_SEPARATE_MATERIALISE") != nullptr;
+        grad_one_stream = getenv("PHYLO_GRAD_ONE_STREAM") != nullptr;
+        grad_two_streams = getenv("PHYLO_GRAD_TWO_STREAMS") != nullptr;
+        no_spin_wait = getenv("PHYLO_NO_SPIN_WAIT") != nullptr;
         const char* w = getenv("PHYLO_PERSIST_WGS");
         persist_wgs = w ? atoi(w) : 0;
         const char* t = getenv("PHYLO_PERSIST_NT");
@@ -153,6 +156,7 @@ struct phylo_ctx {
     // reverse pass finds them on the host without a synchronous copy; and the pinned staging area of its packed integer lists
     int64_t* h_anc_p = nullptr;          // [(R-1)][K]
     double* h_model_p = nullptr;         // pinned image of the model upload (phylo_set_model)
+    uint32_t *h_pub = nullptr, *hd_pub = nullptr;
     uint32_t *hd_csr = nullptr, *hd_anc = nullptr, *hd_child = nullptr, *hd_rad = nullptr;   // device views of h_csr_p, h_anc_p, h_child_p, h_rad_p
     int32_t *h_child_p = nullptr, *h_rad_p = nullptr, *h_csr_p = nullptr;   // [R][K][2], [R][K][N] (twisted), the d_ad_off slab
     size_t h_csr_cap = 0;                // int32 elements
@@ -160,6 +164,12 @@ struct phylo_ctx {
     std::vector<int32_t> h_cur;          // scratch of the counting sorts
     std::vector<int32_t> h_xlists;       // ... of its twisted part
     hipEvent_t evb0 = nullptr, evb1 = nullptr, ev_model = nullptr;
+    // reverse pass: the adopted nodes' chain runs on gstream beside the coefficient chain on `stream`; ev_coeff[r]: C of rank event r done
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_gfork = nullptr, ev_gjoin = nullptr, ev_gup = nullptr;
+    hipStream_t bgstream = nullptr;      // lowest priority: pg_nodes_free in the background of the chains
+    hipEvent_t ev_bgfork = nullptr, ev_bgdone = nullptr;
+    std::vector<hipEvent_t> ev_coeff;
     phylo_stats stats{};
     sweep_run run;
     int n_merge_events = 0;
@@ -209,8 +219,9 @@ int scratch_get(phylo_ctx* ctx, int slot, size_t bytes, void** out) {
         if (b.p) HIPCHK(ctx, hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
-        HIPCHK(ctx, hipMalloc(&b.p, bytes ? bytes : 16));
-        b.bytes = bytes;
+        const size_t want = bytes + bytes / 2 + 16;         // (grow by half: sizes that creep up from call to call -- the chunk counts
+        HIPCHK(ctx, hipMalloc(&b.p, want));                 //  of the reverse pass -- would free and allocate, 60 us, again and again)
+        b.bytes = want;
     }
     *out = b.p;
     return PHYLO_OK;
@@ -269,6 +280,8 @@ void free_sweep_state(phylo_ctx* c) {
     if (c->h_anc_p) (void)hipHostFree(c->h_anc_p);
     if (c->h_child_p) (void)hipHostFree(c->h_child_p);
     if (c->h_rad_p) (void)hipHostFree(c->h_rad_p);
+    if (c->h_pub) (void)hipHostFree(c->h_pub);
+    c->h_pub = c->hd_pub = nullptr;
     c->h_csr_p = c->h_child_p = c->h_rad_p = nullptr;
     c->h_anc_p = nullptr;
     if (c->ev_gcopy) (void)hipEventDestroy(c->ev_gcopy);
@@ -380,6 +393,8 @@ int ensure_graph_state(phylo_ctx* c) {
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_csr, c->h_csr_p, 0));
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_anc, c->h_anc_p, 0));
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_child, c->h_child_p, 0));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_pub, 16));   // log Z-hat (8 bytes) and the timeout word of a sweep that keeps its graph
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_pub, c->h_pub, 0));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_gcopy, hipEventDisableTiming));
         c->d_ad_idx = c->d_ad_off + R * (K + 1);
         c->d_par_off = c->d_ad_idx + R * K;
@@ -394,6 +409,19 @@ int ensure_graph_state(phylo_ctx* c) {
     if (!c->evb0) {
         HIPCHK(c, hipEventCreate(&c->evb0));
         HIPCHK(c, hipEventCreate(&c->evb1));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_gfork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_gjoin, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_gup, hipEventDisableTiming));
+        {
+            int least = 0, greatest = 0;
+            HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(c, hipStreamCreateWithPriority(&c->bgstream, hipStreamNonBlocking, least));
+        }
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_bgfork, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_bgdone, hipEventDisableTiming));
+        c->ev_coeff.assign((size_t)R, nullptr);
+        for (auto& e : c->ev_coeff) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     c->graph_ready = true;
     return PHYLO_OK;
@@ -415,6 +443,21 @@ int launch_scan(phylo_ctx* c, const double* logw, int Kg, int G, uint64_t* cdf, 
 }
 
 // leaf node log-likelihoods sum_s log(pi . leaf[s]) (depend on pi and the leaves)
+// Wait for an event by polling (a blocking hipEventSynchronize wakes the thread tens of microseconds after the event -- a twentieth of
+// a training step, twice per step); after 2 ms of polling, block.
+int wait_event_spin(phylo_ctx* c, hipEvent_t ev) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (; !c->env.no_spin_wait;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return PHYLO_OK;
+        if (e != hipErrorNotReady) return fail(c, PHYLO_EHIP, "hipEventQuery: %s", hipGetErrorString(e));
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        __builtin_ia32_pause();
+    }
+    HIPCHK(c, hipEventSynchronize(ev));
+    return PHYLO_OK;
+}
+
 int refresh_leaf_ll(phylo_ctx* c) {
     if (!(c->have_leaves && c->have_model && c->state_ready)) return PHYLO_OK;
     hipLaunchKernelGGL(pk_row_loglik, dim3(c->N), dim3(PK_COLS), 0, c->stream, c->d_leaves, c->d_pi, c->S,
@@ -507,6 +550,15 @@ int phylo_destroy(phylo_ctx* c) {
     if (c->evb0) (void)hipEventDestroy(c->evb0);
     if (c->evb1) (void)hipEventDestroy(c->evb1);
     if (c->ev_model) (void)hipEventDestroy(c->ev_model);
+    if (c->ev_gfork) (void)hipEventDestroy(c->ev_gfork);
+    if (c->ev_gjoin) (void)hipEventDestroy(c->ev_gjoin);
+    if (c->ev_gup) (void)hipEventDestroy(c->ev_gup);
+    if (c->ev_bgfork) (void)hipEventDestroy(c->ev_bgfork);
+    if (c->ev_bgdone) (void)hipEventDestroy(c->ev_bgdone);
+    if (c->bgstream) (void)hipStreamDestroy(c->bgstream);
+    for (hipEvent_t e : c->ev_coeff)
+        if (e) (void)hipEventDestroy(e);
+    if (c->gstream) (void)hipStreamDestroy(c->gstream);
     if (c->h_model_p) (void)hipHostFree(c->h_model_p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1346,6 +1398,9 @@ int phylo_sweep_finish(phylo_ctx* c) {
         cp.src[0] = (const uint32_t*)c->d_anc; cp.dst[0] = c->hd_anc; cp.n[0] = R > 1 ? (size_t)(R - 1) * c->K * 2 : 0;
         cp.src[1] = (const uint32_t*)c->d_child; cp.dst[1] = c->hd_child; cp.n[1] = (size_t)R * c->K * 2;
         if (twist) { cp.src[2] = (const uint32_t*)c->d_hroots_ad; cp.dst[2] = c->hd_rad; cp.n[2] = (size_t)R * c->K * N; }
+        // ... and what phylo_sweep_fetch would otherwise copy one by one: log Z-hat, the timeout word of the bounded waits
+        cp.src[3] = (const uint32_t*)(c->d_lse + R); cp.dst[3] = c->hd_pub; cp.n[3] = 2;
+        cp.src[4] = (const uint32_t*)(c->d_counter + 1); cp.dst[4] = c->hd_pub + 2; cp.n[4] = 1;
         const size_t words = cp.n[0] + cp.n[1] + cp.n[2];
         hipLaunchKernelGGL(pg_copy_words, dim3((unsigned)(words / 1024 < 1 ? 1 : (words / 1024 > 1024 ? 1024 : words / 1024))), dim3(256), 0, c->stream, cp);
         CHK(launch_check(c, "pg_copy_words"));
@@ -1426,9 +1481,11 @@ int phylo_sweep_fetch(phylo_ctx* c, double* log_weights, double* log_lik, double
     if (!c->swept) return fail(c, PHYLO_ESTATE, "no sweep has been run");
     const size_t R = (size_t)c->N - 1, K = c->K, Kl = c->Kloc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const bool pub = c->last_graph && c->h_pub;            // the sweep kept its graph: its copy kernel left these in pinned memory
     {
         unsigned int tmo = 0;
-        HIPCHK(c, hipMemcpy(&tmo, c->d_counter + 1, sizeof tmo, hipMemcpyDeviceToHost));
+        if (pub) tmo = c->h_pub[2];
+        else HIPCHK(c, hipMemcpy(&tmo, c->d_counter + 1, sizeof tmo, hipMemcpyDeviceToHost));
         if (tmo) {
             HIPCHK(c, hipMemset(c->d_counter + 1, 0, sizeof tmo));
             return fail(c, PHYLO_EHIP, "a bounded wait between workgroups timed out inside a launch; results are invalid");
@@ -1447,7 +1504,10 @@ int phylo_sweep_fetch(phylo_ctx* c, double* log_weights, double* log_lik, double
     if (rbranch) HIPCHK(c, hipMemcpy(rbranch, c->d_br, R * Kl * 8, hipMemcpyDeviceToHost));
     if (merges) HIPCHK(c, hipMemcpy(merges, c->d_merges, R * Kl * 2 * 4, hipMemcpyDeviceToHost));
     if (ancestors && R > 1) HIPCHK(c, hipMemcpy(ancestors, c->d_anc, (R - 1) * Kl * 8, hipMemcpyDeviceToHost));
-    if (logZ) HIPCHK(c, hipMemcpy(logZ, c->d_lse + R, 8, hipMemcpyDeviceToHost));
+    if (logZ) {
+        if (pub) memcpy(logZ, c->h_pub, 8);
+        else HIPCHK(c, hipMemcpy(logZ, c->d_lse + R, 8, hipMemcpyDeviceToHost));
+    }
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->stats.sweep_ms = ms;
@@ -1545,10 +1605,23 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     // a lazy sweep left marks: a node nobody adopted has no parents and alpha = omega, known without any list -- nearly all
     // nodes, done while the host builds the lists
     const bool early_free = rows_form && !twist && c->last_graph_marks;
+    // That launch is 85 us of throughput work nothing waits for before pg_node_finish, while everything else below is a chain of
+    // small dependent launches: it runs on a stream of the lowest priority, in the background of the chains.
+    // (Measured, K = 2048: reverse pass 0.539 -> 0.511 ms with all 898 sites; with 256 sites the launch is 25 us and the extra
+    //  events and the fill launch cost more than they hide, 0.440 -> 0.473 ms: large sweeps only.)
+    const bool bg_free = early_free && !c->env.grad_one_stream && (c->env.grad_two_streams || nn * (size_t)S >= ((size_t)12 << 20));
     if (early_free) {
         g.mark = c->d_mark;
-        hipLaunchKernelGGL(pg_nodes_free, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, c->stream, g, 0);
-        CHK(launch_check(c, "pg_nodes_free"));
+        if (bg_free) {
+            hipLaunchKernelGGL(pg_fill_free, dim3(nrk), dim3(256), 0, c->stream, g);
+            CHK(launch_check(c, "pg_fill_free"));
+            HIPCHK(c, hipEventRecord(c->ev_bgfork, c->stream));
+            // (its launch follows the wait for the sweep's end below: a second queue with a pending wait slows the sweep's own
+            //  dependent launches by half a microsecond each -- 19 us per sweep, measured)
+        } else {
+            hipLaunchKernelGGL(pg_nodes_free, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, c->stream, g, 0);
+            CHK(launch_check(c, "pg_nodes_free"));
+        }
     }
     int tw_launches = 0;
     if (twist) {
@@ -1582,7 +1655,13 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     // ---- integer bookkeeping of the reverse pass: who adopted whom, and which nodes have which parents.  The sweep left the
     //      ancestors and children in pinned host memory (asynchronous copies behind its last launch); the lists are built straight
     //      into the pinned image of the device slab (ad_off | ad_idx | par_off | par_idx | heavy | chunk_beg | chunk_cnt).
-    HIPCHK(c, hipEventSynchronize(c->ev_gcopy));
+    CHK(wait_event_spin(c, c->ev_gcopy));
+    if (bg_free) {
+        HIPCHK(c, hipStreamWaitEvent(c->bgstream, c->ev_bgfork, 0));
+        hipLaunchKernelGGL(pg_nodes_free, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, c->bgstream, g, 3);
+        CHK(launch_check(c, "pg_nodes_free"));
+        HIPCHK(c, hipEventRecord(c->ev_bgdone, c->bgstream));
+    }
     const auto host_t0 = std::chrono::steady_clock::now();
     const int64_t* anc = c->h_anc_p;
     const int32_t* child = c->h_child_p;
@@ -1639,6 +1718,17 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     // early pg_nodes_free has dealt with everybody nobody adopted, the chain runs over the adopted particles alone.
     const size_t ad_ints = (size_t)R * (K + 1) + nn;
     HIPCHK(c, hipMemcpyAsync(c->d_ad_off, c->h_csr_p, ad_ints * 4, hipMemcpyHostToDevice, c->stream));
+    // Two chains of small dependent launches remain, both newest rank event first: the coefficients (here, on the context's
+    // stream) and the adopted nodes' adjoints, which need the coefficients of their own and of later rank events only.  The
+    // second chain runs on its own stream, one rank event behind at most (ev_coeff[r]).
+    // (Small sweeps: the host finishes the parents' lists only when the coefficient chain is over anyway, and the events cost
+    //  13 us: primate.p, K = 2048, 0.542 ms on one stream, 0.555 on two.  DS1, K = 4096: 2.48 -> 2.16 ms.)
+    const bool two = !c->env.grad_one_stream && (c->env.grad_two_streams || nn >= 65536);
+    hipStream_t sB = two ? c->gstream : c->stream;
+    if (two) {
+        HIPCHK(c, hipEventRecord(c->ev_gfork, c->stream));                 // everything launched so far (the early kernels)
+        HIPCHK(c, hipStreamWaitEvent(sB, c->ev_gfork, 0));
+    }
     if (early_free) {
         HIPCHK(c, hipMemcpyAsync(c->d_adp, adp, (size_t)(n_adp ? n_adp : 1) * 4, hipMemcpyHostToDevice, c->stream));
         g.adp = c->d_adp;
@@ -1646,11 +1736,14 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
             hipLaunchKernelGGL(pg_G, dim3(n_adp), dim3(64), 0, c->stream, g);
             CHK(launch_check(c, "pg_G"));
         }
+        if (two) HIPCHK(c, hipEventRecord(c->ev_coeff[R - 1], c->stream));   // (the last rank event has no adopters: C is there)
         for (int r = R - 2; r >= 0; --r) {
             const int na = ev_adp0[r + 1] - ev_adp0[r];
-            if (na == 0) continue;
-            hipLaunchKernelGGL(pg_coeff, dim3(na, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r, (int)ev_adp0[r]);
-            CHK(launch_check(c, "pg_coeff"));
+            if (na > 0) {
+                hipLaunchKernelGGL(pg_coeff, dim3(na, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r, (int)ev_adp0[r]);
+                CHK(launch_check(c, "pg_coeff"));
+            }
+            if (two) HIPCHK(c, hipEventRecord(c->ev_coeff[r], c->stream));
         }
     } else {
         hipLaunchKernelGGL(pg_G, dim3(R * K), dim3(64), 0, c->stream, g);
@@ -1658,6 +1751,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         for (int r = R - 1; r >= 0; --r) {
             hipLaunchKernelGGL(pg_coeff, dim3(K, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r, 0);
             CHK(launch_check(c, "pg_coeff"));
+            if (two) HIPCHK(c, hipEventRecord(c->ev_coeff[r], c->stream));
         }
     }
     hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
@@ -1742,7 +1836,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         auto put = [&](const std::vector<int32_t>& v) { if (!v.empty()) memcpy(w, v.data(), v.size() * 4); w += v.size(); };
         put(xent); put(xc_node); put(xc_beg); put(xc_cnt); put(xc_part); put(xn_id); put(xn_c0); put(xn_nc);
         CHK(scratch_get(c, 6, pk.size() * 4, &d_xlists));
-        HIPCHK(c, hipMemcpyAsync(d_xlists, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_xlists, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, sB));
         CHK(scratch_get(c, 7, tw_max_chunks * (size_t)S * 4 * 8, &d_tpart));
     }
     // ---- parents: entries e = node * 2 + side grouped by child (ascending e).  One pass over the nodes turns the counts into
@@ -1837,8 +1931,9 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         cp.src[1] = c->hd_csr + o1; cp.dst[1] = (uint32_t*)(c->d_ad_off + o1); cp.n[1] = nn + cap + n_chunks;            // heavy | chunk_beg | chunk_cnt
         cp.src[2] = c->hd_csr + o2; cp.dst[2] = (uint32_t*)(c->d_ad_off + o2); cp.n[2] = nn + (size_t)ev_slow0[R];       // slow_flag | slow_idx
         const size_t words = cp.n[0] + cp.n[1] + cp.n[2];
-        hipLaunchKernelGGL(pg_copy_words, dim3((unsigned)(words / 1024 < 1 ? 1 : (words / 1024 > 1024 ? 1024 : words / 1024))), dim3(256), 0, c->stream, cp);
+        hipLaunchKernelGGL(pg_copy_words, dim3((unsigned)(words / 1024 < 1 ? 1 : (words / 1024 > 1024 ? 1024 : words / 1024))), dim3(256), 0, sB, cp);
         CHK(launch_check(c, "pg_copy_words"));
+        if (two) HIPCHK(c, hipEventRecord(c->ev_gup, sB));
     }
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (twist) {
@@ -1856,35 +1951,42 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     int node_launches = early_free ? 1 : 0;
     if (rows_form && !early_free) {                        // the sweep left no marks: every node nobody merged again, now
         ++node_launches;
+        if (two) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gup, 0));   // (needs the flags of the second upload)
         hipLaunchKernelGGL(pg_nodes_free, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, c->stream, g, 1);
         CHK(launch_check(c, "pg_nodes_free"));
     }
     for (int r = R - 1; r >= 0; --r) {
+        if (two) HIPCHK(c, hipStreamWaitEvent(sB, c->ev_coeff[r], 0));
         if (twist && ev_chunk0[r + 1] > ev_chunk0[r]) {
-            hipLaunchKernelGGL(pg_twist_xchunks, dim3(ev_chunk0[r + 1] - ev_chunk0[r], cdiv(S, 256)), dim3(256), 0, c->stream, g, r, (int)ev_chunk0[r]);
+            hipLaunchKernelGGL(pg_twist_xchunks, dim3(ev_chunk0[r + 1] - ev_chunk0[r], cdiv(S, 256)), dim3(256), 0, sB, g, r, (int)ev_chunk0[r]);
             CHK(launch_check(c, "pg_twist_xchunks"));
-            hipLaunchKernelGGL(pg_twist_xsum, dim3(ev_node0[r + 1] - ev_node0[r], cdiv((long)S * 4, 256)), dim3(256), 0, c->stream, g, (int)ev_node0[r], (int)ev_chunk0[r]);
+            hipLaunchKernelGGL(pg_twist_xsum, dim3(ev_node0[r + 1] - ev_node0[r], cdiv((long)S * 4, 256)), dim3(256), 0, sB, g, (int)ev_node0[r], (int)ev_chunk0[r]);
             CHK(launch_check(c, "pg_twist_xsum"));
             tw_launches += 2;
         }
         const int nch = rank_chunk0[r + 1] - rank_chunk0[r];
         if (nch > 0) {
-            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), nch), dim3(256), 0, c->stream, g, (int)rank_chunk0[r]);
+            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), nch), dim3(256), 0, sB, g, (int)rank_chunk0[r]);
             CHK(launch_check(c, "pg_parent_chunks"));
             ++node_launches;
         }
         if (rows_form) {
             const int nslow = ev_slow0[r + 1] - ev_slow0[r];
             if (nslow > 0) {
-                hipLaunchKernelGGL(pg_nodes_rows, dim3(nslow, g.TS), dim3(256), 0, c->stream, g, r, (int)ev_slow0[r]);
+                hipLaunchKernelGGL(pg_nodes_rows, dim3(nslow, g.TS), dim3(256), 0, sB, g, r, (int)ev_slow0[r]);
                 ++node_launches;
             }
         } else {
-            hipLaunchKernelGGL(pg_nodes, dim3(T, K), dim3(256), 0, c->stream, g, r);
+            hipLaunchKernelGGL(pg_nodes, dim3(T, K), dim3(256), 0, sB, g, r);
             ++node_launches;
         }
         CHK(launch_check(c, "pg_nodes"));
     }
+    if (two) {
+        HIPCHK(c, hipEventRecord(c->ev_gjoin, sB));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gjoin, 0));
+    }
+    if (bg_free) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_bgdone, 0));
     hipLaunchKernelGGL(pg_node_finish, dim3(cdiv((long)R * K, 32)), dim3(64), 0, c->stream, g);
     CHK(launch_check(c, "pg_node_finish"));
     hipLaunchKernelGGL(pg_scalars, dim3(nrk), dim3(256), 0, c->stream, g);
@@ -1894,6 +1996,8 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     HIPCHK(c, hipEventRecord(c->evb1, c->stream));
     std::vector<double> out((size_t)2 * R + 20);
     HIPCHK(c, hipMemcpyAsync(out.data(), c->d_gout, out.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_gjoin, c->stream));     // (free again: the stream has waited for it above)
+    CHK(wait_event_spin(c, c->ev_gjoin));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (d_lam_l) memcpy(d_lam_l, out.data(), (size_t)R * 8);
     if (d_lam_r) memcpy(d_lam_r, out.data() + R, (size_t)R * 8);
