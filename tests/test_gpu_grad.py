@@ -299,6 +299,24 @@ def test_gradient_same_with_eager_nodes_and_after_sweep_node():
         assert np.max(np.abs(g_node[key] - g[key])) / scale < 1e-12, key
 
 
+@pytest.mark.parametrize("twisted", [False, True])
+def test_gradient_same_on_two_streams(monkeypatch, twisted):
+    """Large sweeps run pg_nodes_free in the background and the adopted nodes' chain on a second stream (PHYLO_GRAD_TWO_STREAMS
+    forces that at any size; the switches are read by phylo_create): same gradient, bit for bit, as on one stream."""
+    rng = np.random.default_rng(45)
+    N, S, K = 7, 130, 64
+    genome = _codes_genome(rng, N, S)
+    Q, pi, ll, lr = _model(rng, N)
+    run = (lambda: _check_twisted(genome, Q, pi, ll, lr, K=K, M=2, seed=8)) if twisted else (lambda: _check(genome, Q, pi, ll, lr, K=K, seed=8))
+    monkeypatch.setenv('PHYLO_GRAD_TWO_STREAMS', '1')
+    g2 = run()[0]
+    monkeypatch.delenv('PHYLO_GRAD_TWO_STREAMS')
+    monkeypatch.setenv('PHYLO_GRAD_ONE_STREAM', '1')
+    g1 = run()[0]
+    for key in ('d_lam_l', 'd_lam_r', 'd_pi', 'd_Q'):
+        assert np.array_equal(g1[key], g2[key]), key
+
+
 def test_gradient_flat_weights_many_adopted_nodes():
     """All-gap rows: every weight equal, so hundreds of distinct ancestors survive each resampling -- many adopted nodes with few
     parents each (the opposite of the degenerate genealogies of real data)."""
