@@ -156,6 +156,8 @@ struct phylo_ctx {
     // reverse pass finds them on the host without a synchronous copy; and the pinned staging area of its packed integer lists
     int64_t* h_anc_p = nullptr;          // [(R-1)][K]
     double* h_model_p = nullptr;         // pinned image of the model upload (phylo_set_model)
+    double* h_leaves_p = nullptr;        // pinned image of the leaf rows and their codes (phylo_set_leaves)
+    hipEvent_t ev_leaves = nullptr;
     uint32_t *h_pub = nullptr, *hd_pub = nullptr;
     uint32_t *hd_csr = nullptr, *hd_anc = nullptr, *hd_child = nullptr, *hd_rad = nullptr;   // device views of h_csr_p, h_anc_p, h_child_p, h_rad_p
     int32_t *h_child_p = nullptr, *h_rad_p = nullptr, *h_csr_p = nullptr;   // [R][K][2], [R][K][N] (twisted), the d_ad_off slab
@@ -560,6 +562,8 @@ int phylo_destroy(phylo_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->gstream) (void)hipStreamDestroy(c->gstream);
     if (c->h_model_p) (void)hipHostFree(c->h_model_p);
+    if (c->ev_leaves) (void)hipEventDestroy(c->ev_leaves);
+    if (c->h_leaves_p) (void)hipHostFree(c->h_leaves_p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PHYLO_OK;
@@ -568,11 +572,30 @@ int phylo_destroy(phylo_ctx* c) {
 int phylo_set_leaves(phylo_ctx* c, const double* genome) {
     CHK(bind(c));
     if (!genome) return fail(c, PHYLO_EINVAL, "genome_NxSxA is NULL");
-    HIPCHK(c, hipMemcpyAsync(c->d_leaves, genome, (size_t)c->N * c->S * 4 * 8, hipMemcpyHostToDevice, c->stream));
+    // The rows and their 1-byte codes go up from a pinned image that outlives the call, on the context's stream: the call does not
+    // wait for the device (a training step on site minibatches sets new leaves every time).  Only a previous upload still in
+    // flight has to be over before the image is overwritten.
+    const size_t rows = (size_t)c->N * c->S;
+    const bool pinned = rows * 33 <= ((size_t)8 << 20);     // (a large alignment goes up straight from the caller's buffer, and waits)
+    std::vector<uint8_t> codes_v;
+    uint8_t* codes = nullptr;
+    if (pinned) {
+        if (!c->h_leaves_p) {
+            HIPCHK(c, hipHostMalloc((void**)&c->h_leaves_p, rows * 33));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_leaves, hipEventDisableTiming));
+        } else {
+            HIPCHK(c, hipEventSynchronize(c->ev_leaves));
+        }
+        memcpy(c->h_leaves_p, genome, rows * 32);
+        HIPCHK(c, hipMemcpyAsync(c->d_leaves, c->h_leaves_p, rows * 32, hipMemcpyHostToDevice, c->stream));
+        codes = (uint8_t*)c->h_leaves_p + rows * 32;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_leaves, genome, rows * 32, hipMemcpyHostToDevice, c->stream));
+        codes_v.resize(rows);
+        codes = codes_v.data();
+    }
     // one-hot / all-ones rows (the reference's encoding, runner.py:83-96) also get a 1-byte code per site
     {
-        const size_t rows = (size_t)c->N * c->S;
-        std::vector<uint8_t> codes(rows);
         bool ok = true;
         for (size_t i = 0; i < rows && ok; ++i) {
             const double* x = genome + i * 4;
@@ -588,12 +611,13 @@ int phylo_set_leaves(phylo_ctx* c, const double* genome) {
         c->codes_valid = ok;                                  // a property of the data (the twisting contract uses it)
         c->leaves_coded = ok && !c->env.no_leaf_codes;   // the access-path optimisation can be switched off
         c->hist_ready = false;
-        if (ok) HIPCHK(c, hipMemcpy(c->d_leaf_codes, codes.data(), rows, hipMemcpyHostToDevice));
+        if (ok) HIPCHK(c, hipMemcpyAsync(c->d_leaf_codes, codes, rows, hipMemcpyHostToDevice, c->stream));
     }
+    if (pinned) HIPCHK(c, hipEventRecord(c->ev_leaves, c->stream));
     c->have_leaves = true;
     c->last_graph = c->last_graph_twist = false;           // ... and to the leaves
     CHK(refresh_leaf_ll(c));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!pinned) HIPCHK(c, hipStreamSynchronize(c->stream));
     return PHYLO_OK;
 }
 
