@@ -203,6 +203,16 @@ int phylo_sweep_backward(phylo_ctx* ctx, double* d_lam_l, double* d_lam_r, doubl
  * events; row N-1: prologue).  No effect on results; not for timed runs. */
 int phylo_debug_stamps(phylo_ctx* ctx, uint64_t* out, int n);
 
+/* Test hook, no GPU needed: the host side of phylo_sweep_backward's integer lists (phylo_amd/csrc/phylo_revlists.h), run on
+ * caller-supplied ancestors [N-2][K] (int64, as phylo_sweep returns them) and children [N-1][K][2] (node ids: leaf < N, else
+ * N + r K + k).  lookahead_nodes: node ids with look-ahead entries (twisted proposal), may be NULL.  lists receives the slab the
+ * device reads (ad_off | ad_idx | par_off | par_idx | heavy | chunk_beg | chunk_cnt | slow_flag | slow_idx | adp; R (K+1) + 9 R K
+ * + 1 + 2 cap ints, cap = 2 R K / 4 + 1, R = N - 1); meta: n_adp, n_chunks, max_chunks, n_slow, n_par, cap, then ev_adp0[R+1],
+ * rank_chunk0[R+1], ev_slow0[R+1].  tests/test_revlists_cpu.py checks it against a restatement in NumPy. */
+int phylo_debug_reverse_lists(int N, int K, const int64_t* ancestors, const int32_t* child, int early_free, int rows_form,
+                              const int32_t* lookahead_nodes, int n_lookahead, int32_t* lists, int64_t n_lists, int32_t* meta,
+                              int n_meta);
+
 /* Bit-level probe of the device arithmetic contract: op 0 exp(x), 1 log(x), 2 x/y, 3 fma(x,y,x). */
 int phylo_math_probe(phylo_ctx* ctx, int op, const double* x, const double* y, int n, double* out);
 

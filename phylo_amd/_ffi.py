@@ -29,7 +29,7 @@ EXPORTS = [
     "phylo_forest_loglik", "phylo_tree_loglik", "phylo_resample", "phylo_log_zsmc", "phylo_sweep",
     "phylo_sweep_async", "phylo_sweep_batch_async", "phylo_sweep_batch_begin", "phylo_sweep_fetch_logz", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_step_a", "phylo_sweep_step_group", "phylo_sweep_finish", "phylo_sweep_fetch",
     "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
-    "phylo_math_probe", "phylo_debug_stamps",
+    "phylo_math_probe", "phylo_debug_stamps", "phylo_debug_reverse_lists",
     "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_allgather", "phylo_comm_max", "phylo_comm_barrier",
 ]
 
@@ -69,6 +69,40 @@ def _ptr(a):
 
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def debug_reverse_lists(N, K, ancestors, child, early_free=True, rows_form=True, lookahead_nodes=None):
+    """The host side of the reverse pass's integer lists on given ancestors [N-2][K] and children [N-1][K][2] (no GPU needed).
+    Returns a dict of the arrays the device reads plus the per-rank-event offsets."""
+    lib = load()
+    R = N - 1
+    nn = R * K
+    cap = 2 * nn // 4 + 1
+    n_lists = R * (K + 1) + 9 * nn + 1 + 2 * cap
+    lists = np.zeros(n_lists, dtype=np.int32)
+    meta = np.zeros(6 + 3 * (R + 1), dtype=np.int32)
+    anc = None if R < 2 else np.ascontiguousarray(ancestors, dtype=np.int64)
+    ch = np.ascontiguousarray(child, dtype=np.int32)
+    la = None if lookahead_nodes is None or len(lookahead_nodes) == 0 else np.ascontiguousarray(lookahead_nodes, dtype=np.int32)
+    rc = lib.phylo_debug_reverse_lists(C.c_int(N), C.c_int(K), _ptr(anc), _ptr(ch), C.c_int(int(early_free)), C.c_int(int(rows_form)),
+                                       _ptr(la), C.c_int(0 if la is None else la.size), _ptr(lists), C.c_int64(n_lists), _ptr(meta),
+                                       C.c_int(meta.size))
+    if rc:
+        raise PhyloError(rc, lib.phylo_last_error(None).decode())
+    out = {}
+    o = 0
+    for name, n in (("ad_off", R * (K + 1)), ("ad_idx", nn), ("par_off", nn + 1), ("par_idx", 2 * nn), ("heavy", nn), ("chunk_beg", cap),
+                    ("chunk_cnt", cap), ("slow_flag", nn), ("slow_idx", nn), ("adp", nn)):
+        out[name] = lists[o:o + n]
+        o += n
+    out["ad_off"] = out["ad_off"].reshape(R, K + 1)
+    out["ad_idx"] = out["ad_idx"].reshape(R, K)
+    for i, name in enumerate(("n_adp", "n_chunks", "max_chunks", "n_slow", "n_par", "cap")):
+        out[name] = int(meta[i])
+    out["ev_adp0"] = meta[6:6 + R + 1].copy()
+    out["rank_chunk0"] = meta[6 + (R + 1):6 + 2 * (R + 1)].copy()
+    out["ev_slow0"] = meta[6 + 2 * (R + 1):6 + 3 * (R + 1)].copy()
+    return out
 
 
 def device_count():

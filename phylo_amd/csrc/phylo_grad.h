@@ -17,8 +17,7 @@
 
 #define PG_PART 36                     // per-(node, tile) partial sums: Pl_bar[16], Pr_bar[16], pi_bar[4]
 #define PG_NODEG 22                    // per-node results: bl_bar, br_bar, Q_bar[16], pi_bar[4]
-#define PG_PCHUNK 8                    // parents staged in LDS at a time; more parents than this = a heavy node
-#define PG_HCHUNK 32                   // parents per chunk of a heavy node
+#include "phylo_revlists.h"           // PG_PCHUNK, PG_HCHUNK, PG_FREE_PARENT and the host side of the integer lists
 #define PG_NT 256                      // sites per workgroup of pg_nodes (4 steps of 64 sites)
 #define PG_RED_STRIDE 68                // doubles per value row of the LDS reductions: the 48 reading lanes spread over all banks
 
@@ -347,9 +346,8 @@ __device__ __forceinline__ double pg_quad_sum_step(double v) {   // the value of
     return __hiloint2double(hi, lo);
 }
 
-// par_idx entry: (parent node * 2 + side) | PG_FREE_PARENT when the parent's adjoint row is the own term alone and is not stored
-// (rows form: pg_nodes_free); the gather then recomputes it from alpha_parent (staged in shA)
-#define PG_FREE_PARENT (1 << 30)
+// (a par_idx entry carries PG_FREE_PARENT when the parent's adjoint row is not stored: the gather recomputes it from alpha_parent,
+// staged in shA)
 __device__ __forceinline__ double pg_alpha_of(const pg_args& a, int pn) {
     const int rp = pn / a.K;
     return a.C[(size_t)pn * a.N + (a.N - rp - 2)];

@@ -385,8 +385,7 @@ int ensure_graph_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_terms, R * K * 2));
     CHK(dalloc(c, &c->d_gout, 2 * R + 20));
     {   // the integer lists of the reverse pass live in ONE slab, uploaded with one copy per step
-        const size_t cap = 2 * R * K / 4 + 1;
-        c->h_csr_cap = R * (K + 1) + R * K + (R * K + 1) + 2 * R * K + R * K + 2 * cap + 3 * R * K;
+        c->h_csr_cap = pg_lists_ints(R, K);               // (layout: pg_lists_carve, phylo_revlists.h)
         CHK(dalloc(c, &c->d_ad_off, c->h_csr_cap));
         HIPCHK(c, hipHostMalloc((void**)&c->h_csr_p, c->h_csr_cap * 4));
         HIPCHK(c, hipHostMalloc((void**)&c->h_anc_p, (R > 1 ? (R - 1) * K : 1) * 8));
@@ -398,15 +397,10 @@ int ensure_graph_state(phylo_ctx* c) {
         HIPCHK(c, hipHostMalloc((void**)&c->h_pub, 16));   // log Z-hat (8 bytes) and the timeout word of a sweep that keeps its graph
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_pub, c->h_pub, 0));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_gcopy, hipEventDisableTiming));
-        c->d_ad_idx = c->d_ad_off + R * (K + 1);
-        c->d_par_off = c->d_ad_idx + R * K;
-        c->d_par_idx = c->d_par_off + R * K + 1;
-        c->d_heavy = c->d_par_idx + 2 * R * K;
-        c->d_chunk_beg = c->d_heavy + R * K;
-        c->d_chunk_cnt = c->d_chunk_beg + cap;
-        c->d_slow_flag = c->d_chunk_cnt + cap;
-        c->d_slow_idx = c->d_slow_flag + R * K;
-        c->d_adp = c->d_slow_idx + R * K;
+        const pg_lists D = pg_lists_carve(c->d_ad_off, R, K);
+        c->d_ad_idx = D.ad_idx; c->d_par_off = D.par_off; c->d_par_idx = D.par_idx;
+        c->d_heavy = D.heavy; c->d_chunk_beg = D.chunk_beg; c->d_chunk_cnt = D.chunk_cnt;
+        c->d_slow_flag = D.slow_flag; c->d_slow_idx = D.slow_idx; c->d_adp = D.adp;
     }
     if (!c->evb0) {
         HIPCHK(c, hipEventCreate(&c->evb0));
@@ -1689,55 +1683,17 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     const auto host_t0 = std::chrono::steady_clock::now();
     const int64_t* anc = c->h_anc_p;
     const int32_t* child = c->h_child_p;
-    const size_t cap = 2 * nn / 4 + 1;
-    int32_t* ad_off = c->h_csr_p;
-    int32_t* ad_idx = ad_off + (size_t)R * (K + 1);
-    int32_t* par_off = ad_idx + nn;
-    int32_t* par_idx = par_off + nn + 1;
-    int32_t* heavy = par_idx + 2 * nn;
-    int32_t* chunk_beg = heavy + nn;
-    int32_t* chunk_cnt = chunk_beg + cap;
-    int32_t* slow_flag = chunk_cnt + cap;
-    int32_t* slow_idx = slow_flag + nn;
-    int32_t* adp = slow_idx + nn;
-    memset(ad_off, 0, ((size_t)R * (K + 1) + nn + nn + 1) * 4);      // ad_off, ad_idx, par_off
-    memset(slow_flag, 0, nn * 4);
+    const pg_lists L = pg_lists_carve(c->h_csr_p, (size_t)R, (size_t)K);     // (phylo_revlists.h: the builders, tested on the CPU)
+    int32_t* const ad_off = L.ad_off;
+    int32_t* const par_off = L.par_off;
+    int32_t* const heavy = L.heavy;
+    int32_t* const slow_flag = L.slow_flag;
+    int32_t* const adp = L.adp;
+    const size_t cap = L.cap;
+    pg_lists_clear(L, R, K);
     std::vector<int32_t>& cur = c->h_cur;
-    std::vector<int32_t> ev_adp0((size_t)R + 1, 0);        // adopted particles of rank event r: adp[ev_adp0[r] .. ev_adp0[r + 1])
-    int32_t n_adp = 0;
-    // counting sort by ancestor; ties keep ascending k'.  A few ancestors take nearly all the draws, so counters and cursors
-    // are chains of store-to-load forwards on one address: the particles are taken as four contiguous quarters with a counter
-    // row each (four independent chains), whose prefix sums give every quarter its own cursor into an ancestor's list.
-    const int Kq = K / 4;
-    cur.assign((size_t)4 * K, 0);
-    for (int r = 1; r < R; ++r) {
-        int32_t* off = ad_off + (size_t)r * (K + 1);
-        const int64_t* a = anc + (size_t)(r - 1) * K;
-        int32_t* idx = ad_idx + (size_t)r * K;
-        int32_t *c0 = cur.data(), *c1 = c0 + K, *c2 = c1 + K, *c3 = c2 + K;
-        if (r > 1) memset(c0, 0, (size_t)4 * K * 4);
-        for (int k = 0; k < Kq; ++k) {
-            ++c0[a[k]]; ++c1[a[k + Kq]]; ++c2[a[k + 2 * Kq]]; ++c3[a[k + 3 * Kq]];
-        }
-        for (int k = 4 * Kq; k < K; ++k) ++c3[a[k]];       // (the last quarter takes the remainder)
-        ev_adp0[r - 1] = n_adp;
-        int32_t run = 0;
-        for (int x = 0; x < K; ++x) {
-            const int32_t t0 = c0[x], t1 = c1[x], t2 = c2[x], t3 = c3[x];
-            off[x] = run;
-            c0[x] = run; c1[x] = run + t0; c2[x] = run + t0 + t1; c3[x] = run + t0 + t1 + t2;
-            const int32_t tot = (t0 + t1) + (t2 + t3);
-            if (tot) adp[n_adp++] = (r - 1) * K + x;        // somebody adopts (r - 1, x) at rank event r
-            run += tot;
-        }
-        off[K] = run;
-        for (int k = 0; k < Kq; ++k) {
-            idx[c0[a[k]]++] = k; idx[c1[a[k + Kq]]++] = k + Kq; idx[c2[a[k + 2 * Kq]]++] = k + 2 * Kq; idx[c3[a[k + 3 * Kq]]++] = k + 3 * Kq;
-        }
-        for (int k = 4 * Kq; k < K; ++k) idx[c3[a[k]]++] = k;
-    }
-    ev_adp0[R - 1] = ev_adp0[R] = n_adp;
-    if (R == 1) ev_adp0[0] = 0;
+    std::vector<int32_t> ev_adp0;                          // adopted particles of rank event r: adp[ev_adp0[r] .. ev_adp0[r + 1])
+    const int32_t n_adp = pg_build_adopters(R, K, anc, L, cur, ev_adp0);
     // the adopters' lists are all the coefficient chain needs: it runs while the host goes on with the parents' lists.  When the
     // early pg_nodes_free has dealt with everybody nobody adopted, the chain runs over the adopted particles alone.
     const size_t ad_ints = (size_t)R * (K + 1) + nn;
@@ -1863,76 +1819,12 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         HIPCHK(c, hipMemcpyAsync(d_xlists, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, sB));
         CHK(scratch_get(c, 7, tw_max_chunks * (size_t)S * 4 * 8, &d_tpart));
     }
-    // ---- parents: entries e = node * 2 + side grouped by child (ascending e).  One pass over the nodes turns the counts into
-    //      offsets and decides everything per node: heavy nodes (more than PG_PCHUNK parents) get their list cut into chunks,
-    //      numbered within the rank event; nodes with parents, look-ahead entries (twisted) or -- after the early pg_nodes_free --
-    //      adopters are flagged and listed by rank event for pg_nodes_rows; all the others: pg_nodes_free.
-    //      (leaf or internal child is a coin toss in the later rank events: no branch on it -- a leaf counts into a dummy)
-    //      (... and 64 dummies in turn: increments of one address are a chain of store-to-load forwards, 5 cycles each)
-    int32_t dummy[64] = {0};
-    for (size_t e = 0; e < 2 * nn; ++e) {
-        const int32_t ch = child[e];
-        int32_t* p = ch >= N ? par_off + (size_t)(ch - N) + 1 : dummy + (e & 63);
-        ++*p;
-    }
-    std::vector<int32_t> rank_chunk0((size_t)R + 1, 0), ev_slow0((size_t)R + 1, 0);
-    size_t max_chunks = 0, n_chunks = 0;
+    // ---- parents, heavy nodes' chunks, flagged nodes by rank event (pg_build_parents)
+    std::vector<int32_t> rank_chunk0, ev_slow0;
+    const pg_parents_info pinfo = pg_build_parents(N, R, K, child, early_free, rows_form, L, cur, rank_chunk0, ev_slow0);
+    const size_t max_chunks = pinfo.max_chunks, n_chunks = pinfo.n_chunks;
     {
-        int32_t ns = 0, run = 0;
-        for (int r = 0; r < R; ++r) {
-            rank_chunk0[r] = (int32_t)n_chunks;
-            ev_slow0[r] = ns;
-            const int32_t* adn = r + 1 < R ? ad_off + (size_t)(r + 1) * (K + 1) : nullptr;
-            for (int k = 0; k < K; ++k) {
-                const size_t x = (size_t)r * K + k;
-                const int32_t np = par_off[x + 1];           // still the count: the offsets are written behind the read position
-                par_off[x] = run;
-                int32_t f = slow_flag[x];                    // (bit 1 set above: look-ahead entries)
-                if (np) f |= 1;
-                // the early launch skipped every marked (= adopted) node: those without parents join the few flagged ones
-                if (early_free && adn && adn[k + 1] > adn[k]) f |= 4;
-                heavy[x] = -1;
-                if (np > PG_PCHUNK) {
-                    heavy[x] = (int32_t)(n_chunks - rank_chunk0[r]);
-                    for (int32_t b = run; b < run + np; b += PG_HCHUNK) {
-                        chunk_beg[n_chunks] = b;
-                        chunk_cnt[n_chunks] = run + np - b < PG_HCHUNK ? run + np - b : PG_HCHUNK;
-                        ++n_chunks;
-                    }
-                }
-                if (f) {
-                    f |= ns << 3;
-                    slow_idx[ns++] = (int32_t)x;
-                }
-                slow_flag[x] = f;
-                run += np;
-            }
-            if (n_chunks - rank_chunk0[r] > max_chunks) max_chunks = n_chunks - rank_chunk0[r];
-        }
-        par_off[nn] = run;
-        rank_chunk0[R] = (int32_t)n_chunks;
-        ev_slow0[R] = ns;
-        // a parent that goes through pg_nodes_free never stores its adjoint row: the gather recomputes it (PG_FREE_PARENT)
-        // scatter without a branch on leaf / internal (masks, not ?: -- the compiler made a branch of that, mispredicted every other
-        // time in the later rank events): a leaf child advances one of 64 dummy cursors and writes into the tail of par_idx,
-        // which is never used (the 2 K children of rank event 0 are all leaves)
-        cur.resize(nn + 64);
-        memcpy(cur.data(), par_off, nn * 4);
-        const int32_t free_bit = rows_form ? PG_FREE_PARENT : 0;
-        int32_t* curp = cur.data();
-        const int32_t tail = (int32_t)(2 * nn) - 1;
-        int32_t tmask = 1;                                  // dummy slots: the last min(64, 2 K rounded down to a power of two)
-        while (tmask * 2 <= 2 * K && tmask < 64) tmask *= 2;
-        tmask -= 1;
-        for (size_t e = 0; e < 2 * nn; ++e) {              // e = node * 2 + side, ascending
-            const int32_t ch = child[e];
-            const int32_t in = -(int32_t)(ch >= N);          // all ones: internal child
-            const int32_t lane = (int32_t)(e & 63);
-            const int32_t ci = ((ch - N) & in) | (((int32_t)nn + lane) & ~in);
-            const int32_t pos = curp[ci]++;
-            const int32_t di = (pos & in) | ((tail - (lane & tmask)) & ~in);
-            par_idx[di] = (int32_t)e | (slow_flag[e >> 1] ? 0 : free_bit);
-        }
+        const int32_t ns = pinfo.n_slow;
         void* cpart = nullptr;
         CHK(scratch_get(c, 5, max_chunks * (size_t)S * 4 * 8, &cpart));
         g.cpart = (double*)cpart;
@@ -2046,6 +1938,32 @@ int phylo_debug_stamps(phylo_ctx* c, uint64_t* out, int n) {
     if (!out || n < have) return fail(c, PHYLO_EINVAL, "phylo_debug_stamps needs room for N * %d = %d values", PP_NSTAMP, have);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(out, c->d_stamps, (size_t)have * 8, hipMemcpyDeviceToHost));
+    return PHYLO_OK;
+}
+
+int phylo_debug_reverse_lists(int N, int K, const int64_t* ancestors, const int32_t* child, int early_free, int rows_form,
+                              const int32_t* lookahead_nodes, int n_lookahead, int32_t* lists, int64_t n_lists, int32_t* meta, int n_meta) {
+    if (N < 2 || K < 1 || !child || !lists || !meta || (N > 2 && !ancestors) || (n_lookahead > 0 && !lookahead_nodes))
+        return fail(nullptr, PHYLO_EINVAL, "phylo_debug_reverse_lists: bad arguments");
+    const int R = N - 1;
+    if (n_lists < (int64_t)pg_lists_ints((size_t)R, (size_t)K) || n_meta < 6 + 3 * (R + 1))
+        return fail(nullptr, PHYLO_EINVAL, "phylo_debug_reverse_lists: lists needs %zu ints, meta %d", pg_lists_ints((size_t)R, (size_t)K), 6 + 3 * (R + 1));
+    const pg_lists L = pg_lists_carve(lists, (size_t)R, (size_t)K);
+    pg_lists_clear(L, R, K);
+    std::vector<int32_t> cur, ev_adp0, rank_chunk0, ev_slow0;
+    const int32_t n_adp = pg_build_adopters(R, K, ancestors, L, cur, ev_adp0);
+    for (int i = 0; i < n_lookahead; ++i) {
+        if (lookahead_nodes[i] < N || lookahead_nodes[i] >= N + R * K) return fail(nullptr, PHYLO_EINVAL, "phylo_debug_reverse_lists: node id out of range");
+        L.slow_flag[lookahead_nodes[i] - N] |= 2;
+    }
+    const pg_parents_info o = pg_build_parents(N, R, K, child, early_free != 0, rows_form != 0, L, cur, rank_chunk0, ev_slow0);
+    meta[0] = n_adp; meta[1] = (int32_t)o.n_chunks; meta[2] = (int32_t)o.max_chunks; meta[3] = o.n_slow; meta[4] = o.n_par;
+    meta[5] = (int32_t)L.cap;
+    for (int r = 0; r <= R; ++r) {
+        meta[6 + r] = ev_adp0[r];
+        meta[6 + (R + 1) + r] = rank_chunk0[r];
+        meta[6 + 2 * (R + 1) + r] = ev_slow0[r];
+    }
     return PHYLO_OK;
 }
 
