@@ -99,6 +99,10 @@ struct pg_parents_info {
     int32_t n_slow, n_par;             // flagged nodes, parent entries
 };
 
+// (Tried on the builders, measured on a GPU box, not kept: four counter rows per child as in pg_build_adopters -- faster on synthetic
+//  genealogies with many internal children, 0.18 -> 0.26 ms on primate.p's, whose later rank events still merge mostly leaves, because
+//  of the four times larger cursor array; worker threads -- rank events in groups, quarters of the child entries on four cores --
+//  0.6 -> 1.7 ms for DS1 at K = 4096 on the 16-core share of a box.)
 // Parents: entries e = node * 2 + side grouped by child (ascending e).  One pass over the nodes turns the counts into offsets and
 // decides everything per node: heavy nodes (more than PG_PCHUNK parents) get their list cut into chunks of PG_HCHUNK, numbered
 // within the rank event (rank_chunk0); nodes with parents (bit 0), look-ahead entries (bit 1, set by the caller) or -- after the
