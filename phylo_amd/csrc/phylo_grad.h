@@ -1078,7 +1078,7 @@ __device__ __forceinline__ void pg_pbar_site(const double (&x1)[4], const double
         y[j] = u[j] * v[j];
     }
     const double lik = pg_dot4(pi[0], y[0], pi[1], y[1], pi[2], y[2], pi[3], y[3]);
-    const double inv = w / lik;
+    const double inv = w * pg_rcp(lik);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const double g = pi[j] * inv;
@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(256) void pg_twist_xchunks(pg_args a, int r, int ch
                         z[q] = pg_dot4(pv[0], Pme[q * 4], pv[1], Pme[q * 4 + 1], pv[2], Pme[q * 4 + 2], pv[3], Pme[q * 4 + 3]);
                 }
                 const double lik = pg_dot4(x0, z[0], x1, z[1], x2, z[2], x3, z[3]);
-                const double f = tau / lik;
+                const double f = tau * pg_rcp(lik);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) xb[q] = __builtin_fma(f, z[q], xb[q]);
             }
