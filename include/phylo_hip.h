@@ -205,7 +205,7 @@ int phylo_debug_stamps(phylo_ctx* ctx, uint64_t* out, int n);
 
 /* Test hook, no GPU needed: the host side of phylo_sweep_backward's integer lists (phylo_amd/csrc/phylo_revlists.h), run on
  * caller-supplied ancestors [N-2][K] (int64, as phylo_sweep returns them) and children [N-1][K][2] (node ids: leaf < N, else
- * N + r K + k).  lookahead_nodes: node ids with look-ahead entries (twisted proposal), may be NULL.  lists receives the slab the
+ * N + r K + k of an EARLIER rank event: the children of rank event 0 are leaves and are not looked at).  lookahead_nodes: node ids with look-ahead entries (twisted proposal), may be NULL.  lists receives the slab the
  * device reads (ad_off | ad_idx | par_off | par_idx | heavy | chunk_beg | chunk_cnt | slow_flag | slow_idx | adp; R (K+1) + 9 R K
  * + 1 + 2 cap ints, cap = 2 R K / 4 + 1, R = N - 1); meta: n_adp, n_chunks, max_chunks, n_slow, n_par, cap, then ev_adp0[R+1],
  * rank_chunk0[R+1], ev_slow0[R+1].  tests/test_revlists_cpu.py checks it against a restatement in NumPy. */

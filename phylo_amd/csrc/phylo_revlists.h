@@ -115,7 +115,8 @@ inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* chil
     // (leaf or internal child is a coin toss in the later rank events: no branch on it -- a leaf counts into one of 64 dummies in
     //  turn: increments of one address are a chain of store-to-load forwards, 5 cycles each)
     int32_t dummy[64] = {0};
-    for (size_t e = 0; e < 2 * nn; ++e) {
+    const size_t e0 = 2 * (size_t)K;                        // (the children of rank event 0 are leaves: nothing to count)
+    for (size_t e = e0; e < 2 * nn; ++e) {
         const int32_t ch = child[e];
         int32_t* p = ch >= N ? L.par_off + (size_t)(ch - N) + 1 : dummy + (e & 63);
         ++*p;
@@ -168,7 +169,7 @@ inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* chil
     int32_t tmask = 1;                                      // dummy slots: the last min(64, 2 K rounded down to a power of two)
     while (tmask * 2 <= 2 * K && tmask < 64) tmask *= 2;
     tmask -= 1;
-    for (size_t e = 0; e < 2 * nn; ++e) {                  // e = node * 2 + side, ascending
+    for (size_t e = e0; e < 2 * nn; ++e) {                 // e = node * 2 + side, ascending
         const int32_t ch = child[e];
         const int32_t in = -(int32_t)(ch >= N);              // all ones: internal child
         const int32_t lane = (int32_t)(e & 63);
