@@ -92,12 +92,14 @@ int phylo_create(const int* device_ids, int n_gpus, int K, int N, int S, int A, 
 int phylo_destroy(phylo_ctx* ctx);
 
 /* datadict['genome'] [N,S,4] float64 (runner.py:107-115); stored once, not K-replicated
- * (the reference replicates it K-fold at vcsmc.py:479). */
+ * (the reference replicates it K-fold at vcsmc.py:479).  Returns when the caller's buffer has been read (small alignments are
+ * staged in pinned memory and go up behind the call, ordered before every later call on the context). */
 int phylo_set_leaves(phylo_ctx* ctx, const double* genome_NxSxA);
 
 /* Model of VCSMC.__init__ / get_Q / get_stationary_probs (vcsmc.py:119-148), already evaluated by the
  * host: Q row-major 4x4, pi[4], lam_l / lam_r = exp(branch params) [N-1].  jc69_closed_form != 0 uses
- * P_ii = 1/4 + 3/4 e^-t for the JC69 Q instead of the generic Pade expm. */
+ * P_ii = 1/4 + 3/4 e^-t for the JC69 Q instead of the generic Pade expm.  Returns when the 42 numbers are staged;
+ * the upload is ordered before every later call on the context. */
 int phylo_set_model(phylo_ctx* ctx, const double* Q16, const double* pi4, const double* lam_l,
                     const double* lam_r, int jc69_closed_form);
 
