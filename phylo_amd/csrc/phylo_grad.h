@@ -630,18 +630,6 @@ __device__ __forceinline__ void pg_rows_reduce(const double (&acc)[PG_PART], pg_
     if (tid < PG_PART) out[tid] = ((sh.shW[0][tid] + sh.shW[1][tid]) + sh.shW[2][tid]) + sh.shW[3][tid];
 }
 
-// Nodes nobody merged again -- all but the few adopted ones, of ALL rank events in one launch: one WAVE per node (grid R K / 4;
-// a flagged node's wave leaves at once: pg_nodes_rows takes it).  Their adjoint is the own term alone, alpha pi / (pi . X), so one
-// pass over the sites does everything.  The node's own row is recomputed from the children, (L P_l) o (R P_r) as in the forward
-// merge: the stored row is not read, so the sweep need not have stored it (lazy nodes), and the adjoint row is not written
-// either -- a child that gathers from such a parent recomputes the own term (PG_FREE_PARENT), which costs less than the HBM
-// round trip of the row.  Children are leaves or adopted nodes: a few rows, read by thousands of nodes (L2).  A wave per node, not a workgroup: the chain node -> children -> rows -> 36 sums is latency,
-// and sixteen independent chains per CU hide it where four workgroups did not (132 us per launch at K = 2048, N = 12); the rows
-// of the next 64 sites are loaded while the current ones are used.
-// phase 0 (before the host has built any list; needs the marks of a lazy sweep): the nodes nobody adopted -- no adopters, so
-// alpha = G = omega exactly, and no parents; the host then flags every adopted node for pg_nodes_rows (a marked node that was not
-// adopted -- phylo_sweep_node marks what it writes -- would be lost: the marks then do not count, phase 1).
-// phase 1 (after the lists, a sweep without marks): every node without parents.
 // G = C = omega for every (r, k) nobody adopted (see pg_nodes_free, phase 0): as a launch of its own, thread per (r, k), when the
 // long pg_nodes_free runs in the background on another stream and the coefficient chain must not wait for it (phase 3 there).
 __global__ __launch_bounds__(256) void pg_fill_free(pg_args a) {
@@ -653,6 +641,21 @@ __global__ __launch_bounds__(256) void pg_fill_free(pg_args a) {
     for (int slot = 0; slot < a.N - r - 1; ++slot) a.C[t * a.N + slot] = om;
 }
 
+// Nodes nobody merged again -- all but the few adopted ones, of ALL rank events in one launch: one WAVE per node (grid R K / 4;
+// a flagged node's wave leaves at once: pg_nodes_rows takes it).  Their adjoint is the own term alone, alpha pi / (pi . X), so one
+// pass over the sites does everything.  The node's own row is recomputed from the children, (L P_l) o (R P_r) as in the forward
+// merge: the stored row is not read, so the sweep need not have stored it (lazy nodes), and the adjoint row is not written
+// either -- a child that gathers from such a parent recomputes the own term (PG_FREE_PARENT), which costs less than the HBM
+// round trip of the row.  Children are leaves or adopted nodes: a few rows, read by thousands of nodes (L2).  A wave per node,
+// not a workgroup: the chain node -> children -> rows -> 36 sums is latency, and sixteen independent chains per CU hide it
+// where four workgroups did not (132 us per launch at K = 2048, N = 12); the rows of the next 64 sites are loaded while the
+// current ones are used.
+// phase 0 (before the host has built any list; needs the marks of a lazy sweep): the nodes nobody adopted -- no adopters, so
+//   alpha = G = omega exactly, and no parents; it also writes G = C = omega for them.  The host then flags every adopted node for
+//   pg_nodes_rows.  (A marked node that was not adopted -- phylo_sweep_node marks what it writes -- would be lost: after that
+//   call the marks do not count and phase 1 is used.)
+// phase 3: the same nodes, without the G / C writes (pg_fill_free has made them): the background launch.
+// phase 1 (after the lists; a sweep without usable marks): every node without a flag.
 __global__ __launch_bounds__(256, 3) void pg_nodes_free(pg_args a, int phase) {
     __shared__ double red[4][12][PG_RED_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63;
