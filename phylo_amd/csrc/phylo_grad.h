@@ -74,6 +74,10 @@ struct pg_args {
     const int32_t* adp;                // NULL, or the adopted (r * K + k), grouped by rank event: pg_G / pg_coeff run on these alone --
                                        // the early pg_nodes_free has written G = C = omega for everybody else
     const unsigned int* mark;          // [R][K] or NULL: node (r, k) was adopted at rank event r + 1 (the lazy sweep's marks)
+    int alpha_om;                      // alpha of a FREE parent is omega itself (the early pg_nodes_free: free = nobody adopted it): the
+                                       // gathers then need nothing of the coefficient chain
+    int chunks_free_only;              // pg_parent_chunks sums the entries of free parents only (one launch for all rank events);
+                                       // pg_nodes_rows adds the flagged parents' entries, which end a heavy node's list
     double* slowpart;                  // [flagged nodes][TS][PG_PART] (rows form; else NULL): their partial sums, TS tiles of 256 sites
     int TS;
     double *om, *G;                    // [R][K]
@@ -349,6 +353,7 @@ __device__ __forceinline__ double pg_quad_sum_step(double v) {   // the value of
 // (a par_idx entry carries PG_FREE_PARENT when the parent's adjoint row is not stored: the gather recomputes it from alpha_parent,
 // staged in shA)
 __device__ __forceinline__ double pg_alpha_of(const pg_args& a, int pn) {
+    if (a.alpha_om) return a.om[pn];                        // (read for free parents only; a flagged parent's row is stored)
     const int rp = pn / a.K;
     return a.C[(size_t)pn * a.N + (a.N - rp - 2)];
 }
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(256) void pg_parent_chunks(pg_args a, int chunk0) {
         for (int e = 0; e < PG_PCHUNK; ++e) {
             if (e < nc) {                                    // wave-uniform
                 const int enc = __builtin_amdgcn_readfirstlane(shE[e0 + e]);
+                if (a.chunks_free_only && !(enc & PG_FREE_PARENT)) continue;   // a flagged parent: pg_nodes_rows adds it
                 const int side = enc & 1;
                 const double* Psib = shP[e0 + e] + (1 - side) * 16;
                 const double* Pme = shP[e0 + e] + side * 16;
@@ -747,7 +753,7 @@ __global__ __launch_bounds__(256, 3) void pg_nodes_free(pg_args a, int phase) {
 // of latencies, not throughput: every load of a thread is issued as early as possible, nothing goes through memory between the
 // adjoint row and the matrix adjoints, and the register count (occupancy 2) does not matter.  The 36 sums of a (node, tile) go
 // to slowpart; pg_node_finish adds the tiles in order.
-__global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int slow0) {
+__global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int slow0, int chunk0) {
     __shared__ double shP[PG_PCHUNK][32];
     __shared__ int shE[PG_PCHUNK];
     __shared__ int shSib[PG_PCHUNK];
@@ -774,7 +780,23 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
     const int hv = a.heavy_first[node];
     const int np = pend - pbeg;
     const int nch = hv >= 0 ? (np + PG_HCHUNK - 1) / PG_HCHUNK : 0;
-    if (hv < 0 && np > 0) pg_stage_parents(a, pbeg, np, shP, shE, shSib, shA);
+    // the entries gathered here, PG_PCHUNK at a time through LDS: a light node's whole list; of a heavy node (its free parents'
+    // entries are in the chunk sums) the flagged parents' entries, which end the list -- counted by a ballot over its last entries
+    int tail_beg = pbeg, tail_n = hv < 0 ? np : 0;
+    if (hv >= 0 && a.chunks_free_only) {
+        int cnt = 0;
+        for (int base = pend;; base -= 64) {
+            const int i = base - 1 - (tid & 63);
+            const bool fr = i < pbeg || (a.par_idx[i] & PG_FREE_PARENT) != 0;
+            const unsigned long long m = __ballot(fr);
+            const int run = m ? __ffsll((long long)m) - 1 : 64;
+            cnt += run;
+            if (run < 64) break;
+        }
+        tail_n = cnt;
+        tail_beg = pend - cnt;
+    }
+    if (tail_n > 0) pg_stage_parents(a, tail_beg, tail_n < PG_PCHUNK ? tail_n : PG_PCHUNK, shP, shE, shSib, shA);
     const double* Pu = a.Pmat + node * 32;
     double Pl[16], Pr[16];
 #pragma unroll
@@ -788,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
 #pragma unroll
     for (int j = 0; j < 4; ++j) xb[j] = pi[j] * inv + x0[j];
     if (hv >= 0) {                                           // chunk sums, sixteen rows in flight (added in order)
-        const double* cp = a.cpart + (size_t)hv * row + so;
+        const double* cp = a.cpart + (size_t)(chunk0 + hv) * row + so;   // (chunk0: the rank event's first chunk when cpart holds all events')
         for (int c0 = 0; c0 < nch; c0 += 16) {
             double q[16][4];
 #pragma unroll
@@ -804,12 +826,19 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
                     for (int j = 0; j < 4; ++j) xb[j] = xb[j] + q[u][j];
                 }
         }
-    } else {
-        for (int e0 = 0; e0 < np; e0 += 4) {                 // the light node's own parents, four at a time, loads first
+    }
+    for (int st = 0; st < tail_n; st += PG_PCHUNK) {
+        const int nc = tail_n - st < PG_PCHUNK ? tail_n - st : PG_PCHUNK;
+        if (st > 0) {                                        // (more than PG_PCHUNK flagged parents: rare)
+            __syncthreads();
+            pg_stage_parents(a, tail_beg + st, nc, shP, shE, shSib, shA);
+            __syncthreads();
+        }
+        for (int e0 = 0; e0 < nc; e0 += 4) {                 // four at a time, loads first
             double xp[4][4], sb[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int ee = e0 + u < np ? e0 + u : np - 1;
+                const int ee = e0 + u < nc ? e0 + u : nc - 1;
                 const int enc = __builtin_amdgcn_readfirstlane(shE[ee]);
                 const double* sbp = pg_row(a, shSib[ee]) + so;
 #pragma unroll
@@ -822,7 +851,7 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (e0 + u < np) {
+                if (e0 + u < nc) {
                     const int e = e0 + u;
                     const int enc = __builtin_amdgcn_readfirstlane(shE[e]);
                     const int side = enc & 1;

@@ -1623,6 +1623,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     // a lazy sweep left marks: a node nobody adopted has no parents and alpha = omega, known without any list -- nearly all
     // nodes, done while the host builds the lists
     const bool early_free = rows_form && !twist && c->last_graph_marks;
+    g.alpha_om = early_free ? 1 : 0;                       // a free parent then is a node nobody adopted: alpha = omega
     // That launch is 85 us of throughput work nothing waits for before pg_node_finish, while everything else below is a chain of
     // small dependent launches: it runs on a stream of the lowest priority, in the background of the chains.
     // (Measured, K = 2048: reverse pass 0.539 -> 0.511 ms with all 898 sites; with 256 sites the launch is 25 us and the extra
@@ -1826,8 +1827,11 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     {
         const int32_t ns = pinfo.n_slow;
         void* cpart = nullptr;
-        CHK(scratch_get(c, 5, max_chunks * (size_t)S * 4 * 8, &cpart));
+        // rows form: the chunk sums of ALL rank events are produced by one launch (free parents only: nothing of the chain is
+        // needed for them), so the buffer holds every chunk; else one rank event's at a time
+        CHK(scratch_get(c, 5, (rows_form ? n_chunks : max_chunks) * (size_t)S * 4 * 8, &cpart));
         g.cpart = (double*)cpart;
+        g.chunks_free_only = rows_form ? 1 : 0;
         g.TS = cdiv(S, 256);
         {
             void* fp = nullptr;
@@ -1850,6 +1854,20 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         hipLaunchKernelGGL(pg_copy_words, dim3((unsigned)(words / 1024 < 1 ? 1 : (words / 1024 > 1024 ? 1024 : words / 1024))), dim3(256), 0, sB, cp);
         CHK(launch_check(c, "pg_copy_words"));
         if (two) HIPCHK(c, hipEventRecord(c->ev_gup, sB));
+    }
+    if (rows_form && n_chunks > 0) {
+        // The parents of a heavy node are nearly all nodes nobody merged again: their share of the node's adjoint needs their
+        // alpha and nothing else -- omega itself after the early pg_nodes_free, else the finished coefficients.  ONE launch sums
+        // them for the chunks of all rank events; the chain below is then pg_nodes_rows alone, which adds the flagged parents.
+        if (two && !early_free) HIPCHK(c, hipStreamWaitEvent(sB, c->ev_coeff[0], 0));
+        const size_t rowlen = (size_t)S * 4;
+        for (size_t cbeg = 0; cbeg < n_chunks; cbeg += 65535) {
+            const size_t cn = n_chunks - cbeg < 65535 ? n_chunks - cbeg : 65535;
+            pg_args g2 = g;
+            g2.cpart = g.cpart + cbeg * rowlen;
+            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), (unsigned)cn), dim3(256), 0, sB, g2, (int)cbeg);
+            CHK(launch_check(c, "pg_parent_chunks"));
+        }
     }
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (twist) {
@@ -1880,7 +1898,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
             CHK(launch_check(c, "pg_twist_xsum"));
             tw_launches += 2;
         }
-        const int nch = rank_chunk0[r + 1] - rank_chunk0[r];
+        const int nch = rows_form ? 0 : rank_chunk0[r + 1] - rank_chunk0[r];   // (rows form: summed above, all rank events at once)
         if (nch > 0) {
             hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), nch), dim3(256), 0, sB, g, (int)rank_chunk0[r]);
             CHK(launch_check(c, "pg_parent_chunks"));
@@ -1889,7 +1907,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         if (rows_form) {
             const int nslow = ev_slow0[r + 1] - ev_slow0[r];
             if (nslow > 0) {
-                hipLaunchKernelGGL(pg_nodes_rows, dim3(nslow, g.TS), dim3(256), 0, sB, g, r, (int)ev_slow0[r]);
+                hipLaunchKernelGGL(pg_nodes_rows, dim3(nslow, g.TS), dim3(256), 0, sB, g, r, (int)ev_slow0[r], (int)rank_chunk0[r]);
                 ++node_launches;
             }
         } else {

@@ -5,6 +5,7 @@
 // functions run under phylo_debug_reverse_lists for the CPU tests (tests/test_revlists_cpu.py checks them against a restatement in
 // NumPy).  The layout of the slab is the one the device reads (pg_args in phylo_grad.h).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -160,23 +161,33 @@ inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* chil
     ev_slow0[R] = ns;
     // scatter without a branch on leaf / internal (masks, not ?: -- the compiler made a branch of that, mispredicted every other
     // time in the later rank events): a leaf child advances one of 64 dummy cursors and writes into the tail of par_idx,
-    // which is never used (the 2 K children of rank event 0 are all leaves)
-    cur.resize(nn + 64);
-    memcpy(cur.data(), L.par_off, nn * 4);
+    // which is never used (the 2 K children of rank event 0 are all leaves).
+    // Rows form: the entries of FREE parents (no flag: their adjoint is recomputed, nothing of the chain is needed) fill a child's
+    // list from the front, ascending; the few entries of flagged parents from the back, so the list ends with them in descending
+    // order -- pg_parent_chunks_all sums the free ones of every rank event in one launch, pg_nodes_rows walks the tail.
+    cur.resize(2 * (nn + 64));
+    int32_t* front = cur.data();
+    int32_t* back = front + nn + 64;
+    memcpy(front, L.par_off, nn * 4);
+    for (size_t x = 0; x < nn; ++x) back[x] = L.par_off[x + 1] - 1;
     const int32_t free_bit = rows_form ? PG_FREE_PARENT : 0;
-    int32_t* curp = cur.data();
     const int32_t tail = (int32_t)(2 * nn) - 1;
     int32_t tmask = 1;                                      // dummy slots: the last min(64, 2 K rounded down to a power of two)
     while (tmask * 2 <= 2 * K && tmask < 64) tmask *= 2;
     tmask -= 1;
+    const ptrdiff_t rowlen = (ptrdiff_t)(nn + 64);
     for (size_t e = e0; e < 2 * nn; ++e) {                 // e = node * 2 + side, ascending
         const int32_t ch = child[e];
         const int32_t in = -(int32_t)(ch >= N);              // all ones: internal child
         const int32_t lane = (int32_t)(e & 63);
         const int32_t ci = ((ch - N) & in) | (((int32_t)nn + lane) & ~in);
-        const int32_t pos = curp[ci]++;
+        const int32_t fl = L.slow_flag[e >> 1] != 0;         // the parent is a flagged node
+        const int32_t tob = fl & (rows_form ? 1 : 0);        // 1: from the back
+        int32_t* cp = front + (ptrdiff_t)tob * rowlen + ci;
+        const int32_t pos = *cp;
+        *cp = pos + 1 - 2 * tob;
         const int32_t di = (pos & in) | ((tail - (lane & tmask)) & ~in);
-        L.par_idx[di] = (int32_t)e | (L.slow_flag[e >> 1] ? 0 : free_bit);
+        L.par_idx[di] = (int32_t)e | (fl ? 0 : free_bit);
     }
     pg_parents_info o;
     o.n_chunks = n_chunks; o.max_chunks = max_chunks; o.n_slow = ns; o.n_par = run;

@@ -86,12 +86,18 @@ def test_lists_match_restatement(N, K, survivors, early, rows, seed):
         assert list(out["adp"][out["ev_adp0"][r]:out["ev_adp0"][r + 1]]) == ev, r
         adp_ref += ev
     assert out["n_adp"] == len(adp_ref)
-    # parents, ascending entries; a parent without flags is marked free in the rows form
+    # parents; a parent without flags is marked free in the rows form
     po = out["par_off"]
     assert po[0] == 0 and po[nn] == out["n_par"] == sum(len(p) for p in parents)
     for x in range(nn):
         got = out["par_idx"][po[x]:po[x + 1]]
-        assert list(got & (FREE - 1)) == parents[x], x
+        if rows:       # entries of free parents first, ascending; those of flagged parents behind them, descending
+            free = [e for e in parents[x] if flags[e >> 1] == 0]
+            slow = [e for e in parents[x] if flags[e >> 1] != 0]
+            want = free + slow[::-1]
+        else:
+            want = parents[x]
+        assert list(got & (FREE - 1)) == want, x
         for e in got:
             assert bool(e & FREE) == (rows and flags[(int(e) & (FREE - 1)) >> 1] == 0)
     # flags, lists of flagged nodes by rank event, chunks of the heavy nodes numbered within the rank event
