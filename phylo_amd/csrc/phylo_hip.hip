@@ -1693,23 +1693,84 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     const size_t cap = L.cap;
     pg_lists_clear(L, R, K);
     std::vector<int32_t>& cur = c->h_cur;
+    // Two chains of small dependent launches remain, both newest rank event first: the coefficients (on the context's stream) and
+    // the adopted nodes' adjoints, which need the coefficients of their own and of later rank events only (ev_coeff[r]), on a
+    // second stream.  After the early pg_nodes_free the parents' lists are built FIRST (they need of the adopters only who was
+    // adopted: pg_mark_adopted), so that the one launch over all heavy nodes' free parents runs while the host sorts the adopters
+    // and beside the coefficient chain; the adopted nodes' chain then follows the coefficients one rank event behind.
+    // (Without that reordering and for small sweeps two streams gain nothing -- the host finishes the parents' lists only when the
+    //  coefficient chain is over -- and the events cost 13 us: primate.p, K = 2048, 0.542 against 0.555 ms; DS1, K = 4096: 2.48 -> 2.16.)
+    // (Measured, K = 2048: reverse pass 0.522 -> 0.476 ms with all 898 sites, 0.455 -> 0.466 with 256: large sweeps only, like the
+    //  background launch.)
+    const bool reorder = bg_free;
+    const bool two = !c->env.grad_one_stream && (c->env.grad_two_streams || nn >= 65536 || reorder);
+    hipStream_t sB = two ? c->gstream : c->stream;
+    if (two) {
+        HIPCHK(c, hipEventRecord(c->ev_gfork, c->stream));                 // everything launched so far (the early kernels)
+        HIPCHK(c, hipStreamWaitEvent(sB, c->ev_gfork, 0));
+    }
+    std::vector<int32_t> rank_chunk0, ev_slow0;
+    pg_parents_info pinfo{};
+    size_t max_chunks = 0, n_chunks = 0;
+    if (early_free) pg_mark_adopted(R, K, anc, L);
+    auto parents_block = [&]() -> int {
+    // ---- parents, heavy nodes' chunks, flagged nodes by rank event (pg_build_parents)
+    pinfo = pg_build_parents(N, R, K, child, rows_form, L, cur, rank_chunk0, ev_slow0);
+    max_chunks = pinfo.max_chunks; n_chunks = pinfo.n_chunks;
+    {
+        const int32_t ns = pinfo.n_slow;
+        void* cpart = nullptr;
+        // rows form: the chunk sums of ALL rank events are produced by one launch (free parents only: nothing of the chain is
+        // needed for them), so the buffer holds every chunk; else one rank event's at a time
+        CHK(scratch_get(c, 5, (rows_form ? n_chunks : max_chunks) * (size_t)S * 4 * 8, &cpart));
+        g.cpart = (double*)cpart;
+        g.chunks_free_only = rows_form ? 1 : 0;
+        g.TS = cdiv(S, 256);
+        {
+            void* fp = nullptr;
+            CHK(scratch_get(c, 2, ((nn + 31) / 32) * 20 * 8, &fp));
+            g.fin_part = (double*)fp;
+        }
+        if (rows_form) {
+            void* sp = nullptr;
+            CHK(scratch_get(c, 3, (size_t)(ns ? ns : 1) * g.TS * PG_PART * 8, &sp));
+            g.slowpart = (double*)sp;
+        }
+    }
+    {   // what was used of everything between the adopters' lists and the adopted particles, by a kernel (pg_copy_words)
+        pg_copy3 cp{};
+        const size_t o0 = (size_t)(par_off - ad_off), o1 = (size_t)(heavy - ad_off), o2 = (size_t)(slow_flag - ad_off);
+        cp.src[0] = c->hd_csr + o0; cp.dst[0] = (uint32_t*)(c->d_ad_off + o0); cp.n[0] = nn + 1 + (size_t)par_off[nn];   // par_off | par_idx
+        cp.src[1] = c->hd_csr + o1; cp.dst[1] = (uint32_t*)(c->d_ad_off + o1); cp.n[1] = nn + cap + n_chunks;            // heavy | chunk_beg | chunk_cnt
+        cp.src[2] = c->hd_csr + o2; cp.dst[2] = (uint32_t*)(c->d_ad_off + o2); cp.n[2] = nn + (size_t)ev_slow0[R];       // slow_flag | slow_idx
+        const size_t words = cp.n[0] + cp.n[1] + cp.n[2];
+        hipLaunchKernelGGL(pg_copy_words, dim3((unsigned)(words / 1024 < 1 ? 1 : (words / 1024 > 1024 ? 1024 : words / 1024))), dim3(256), 0, sB, cp);
+        CHK(launch_check(c, "pg_copy_words"));
+        if (two) HIPCHK(c, hipEventRecord(c->ev_gup, sB));
+    }
+    if (rows_form && n_chunks > 0) {
+        // The parents of a heavy node are nearly all nodes nobody merged again: their share of the node's adjoint needs their
+        // alpha and nothing else -- omega itself after the early pg_nodes_free, else the finished coefficients.  ONE launch sums
+        // them for the chunks of all rank events; the chain below is then pg_nodes_rows alone, which adds the flagged parents.
+        if (two && !early_free) HIPCHK(c, hipStreamWaitEvent(sB, c->ev_coeff[0], 0));
+        const size_t rowlen = (size_t)S * 4;
+        for (size_t cbeg = 0; cbeg < n_chunks; cbeg += 65535) {
+            const size_t cn = n_chunks - cbeg < 65535 ? n_chunks - cbeg : 65535;
+            pg_args g2 = g;
+            g2.cpart = g.cpart + cbeg * rowlen;
+            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), (unsigned)cn), dim3(256), 0, sB, g2, (int)cbeg);
+            CHK(launch_check(c, "pg_parent_chunks"));
+        }
+    }
+        return PHYLO_OK;
+    };
+    if (reorder) CHK(parents_block());
     std::vector<int32_t> ev_adp0;                          // adopted particles of rank event r: adp[ev_adp0[r] .. ev_adp0[r + 1])
     const int32_t n_adp = pg_build_adopters(R, K, anc, L, cur, ev_adp0);
     // the adopters' lists are all the coefficient chain needs: it runs while the host goes on with the parents' lists.  When the
     // early pg_nodes_free has dealt with everybody nobody adopted, the chain runs over the adopted particles alone.
     const size_t ad_ints = (size_t)R * (K + 1) + nn;
     HIPCHK(c, hipMemcpyAsync(c->d_ad_off, c->h_csr_p, ad_ints * 4, hipMemcpyHostToDevice, c->stream));
-    // Two chains of small dependent launches remain, both newest rank event first: the coefficients (here, on the context's
-    // stream) and the adopted nodes' adjoints, which need the coefficients of their own and of later rank events only.  The
-    // second chain runs on its own stream, one rank event behind at most (ev_coeff[r]).
-    // (Small sweeps: the host finishes the parents' lists only when the coefficient chain is over anyway, and the events cost
-    //  13 us: primate.p, K = 2048, 0.542 ms on one stream, 0.555 on two.  DS1, K = 4096: 2.48 -> 2.16 ms.)
-    const bool two = !c->env.grad_one_stream && (c->env.grad_two_streams || nn >= 65536);
-    hipStream_t sB = two ? c->gstream : c->stream;
-    if (two) {
-        HIPCHK(c, hipEventRecord(c->ev_gfork, c->stream));                 // everything launched so far (the early kernels)
-        HIPCHK(c, hipStreamWaitEvent(sB, c->ev_gfork, 0));
-    }
     if (early_free) {
         HIPCHK(c, hipMemcpyAsync(c->d_adp, adp, (size_t)(n_adp ? n_adp : 1) * 4, hipMemcpyHostToDevice, c->stream));
         g.adp = c->d_adp;
@@ -1820,55 +1881,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         HIPCHK(c, hipMemcpyAsync(d_xlists, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, sB));
         CHK(scratch_get(c, 7, tw_max_chunks * (size_t)S * 4 * 8, &d_tpart));
     }
-    // ---- parents, heavy nodes' chunks, flagged nodes by rank event (pg_build_parents)
-    std::vector<int32_t> rank_chunk0, ev_slow0;
-    const pg_parents_info pinfo = pg_build_parents(N, R, K, child, early_free, rows_form, L, cur, rank_chunk0, ev_slow0);
-    const size_t max_chunks = pinfo.max_chunks, n_chunks = pinfo.n_chunks;
-    {
-        const int32_t ns = pinfo.n_slow;
-        void* cpart = nullptr;
-        // rows form: the chunk sums of ALL rank events are produced by one launch (free parents only: nothing of the chain is
-        // needed for them), so the buffer holds every chunk; else one rank event's at a time
-        CHK(scratch_get(c, 5, (rows_form ? n_chunks : max_chunks) * (size_t)S * 4 * 8, &cpart));
-        g.cpart = (double*)cpart;
-        g.chunks_free_only = rows_form ? 1 : 0;
-        g.TS = cdiv(S, 256);
-        {
-            void* fp = nullptr;
-            CHK(scratch_get(c, 2, ((nn + 31) / 32) * 20 * 8, &fp));
-            g.fin_part = (double*)fp;
-        }
-        if (rows_form) {
-            void* sp = nullptr;
-            CHK(scratch_get(c, 3, (size_t)(ns ? ns : 1) * g.TS * PG_PART * 8, &sp));
-            g.slowpart = (double*)sp;
-        }
-    }
-    {   // what was used of everything between the adopters' lists and the adopted particles, by a kernel (pg_copy_words)
-        pg_copy3 cp{};
-        const size_t o0 = (size_t)(par_off - ad_off), o1 = (size_t)(heavy - ad_off), o2 = (size_t)(slow_flag - ad_off);
-        cp.src[0] = c->hd_csr + o0; cp.dst[0] = (uint32_t*)(c->d_ad_off + o0); cp.n[0] = nn + 1 + (size_t)par_off[nn];   // par_off | par_idx
-        cp.src[1] = c->hd_csr + o1; cp.dst[1] = (uint32_t*)(c->d_ad_off + o1); cp.n[1] = nn + cap + n_chunks;            // heavy | chunk_beg | chunk_cnt
-        cp.src[2] = c->hd_csr + o2; cp.dst[2] = (uint32_t*)(c->d_ad_off + o2); cp.n[2] = nn + (size_t)ev_slow0[R];       // slow_flag | slow_idx
-        const size_t words = cp.n[0] + cp.n[1] + cp.n[2];
-        hipLaunchKernelGGL(pg_copy_words, dim3((unsigned)(words / 1024 < 1 ? 1 : (words / 1024 > 1024 ? 1024 : words / 1024))), dim3(256), 0, sB, cp);
-        CHK(launch_check(c, "pg_copy_words"));
-        if (two) HIPCHK(c, hipEventRecord(c->ev_gup, sB));
-    }
-    if (rows_form && n_chunks > 0) {
-        // The parents of a heavy node are nearly all nodes nobody merged again: their share of the node's adjoint needs their
-        // alpha and nothing else -- omega itself after the early pg_nodes_free, else the finished coefficients.  ONE launch sums
-        // them for the chunks of all rank events; the chain below is then pg_nodes_rows alone, which adds the flagged parents.
-        if (two && !early_free) HIPCHK(c, hipStreamWaitEvent(sB, c->ev_coeff[0], 0));
-        const size_t rowlen = (size_t)S * 4;
-        for (size_t cbeg = 0; cbeg < n_chunks; cbeg += 65535) {
-            const size_t cn = n_chunks - cbeg < 65535 ? n_chunks - cbeg : 65535;
-            pg_args g2 = g;
-            g2.cpart = g.cpart + cbeg * rowlen;
-            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), (unsigned)cn), dim3(256), 0, sB, g2, (int)cbeg);
-            CHK(launch_check(c, "pg_parent_chunks"));
-        }
-    }
+    if (!reorder) CHK(parents_block());
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (twist) {
         const int32_t* xl = (const int32_t*)d_xlists;
@@ -1970,11 +1983,12 @@ int phylo_debug_reverse_lists(int N, int K, const int64_t* ancestors, const int3
     pg_lists_clear(L, R, K);
     std::vector<int32_t> cur, ev_adp0, rank_chunk0, ev_slow0;
     const int32_t n_adp = pg_build_adopters(R, K, ancestors, L, cur, ev_adp0);
+    if (early_free) pg_mark_adopted(R, K, ancestors, L);
     for (int i = 0; i < n_lookahead; ++i) {
         if (lookahead_nodes[i] < N || lookahead_nodes[i] >= N + R * K) return fail(nullptr, PHYLO_EINVAL, "phylo_debug_reverse_lists: node id out of range");
         L.slow_flag[lookahead_nodes[i] - N] |= 2;
     }
-    const pg_parents_info o = pg_build_parents(N, R, K, child, early_free != 0, rows_form != 0, L, cur, rank_chunk0, ev_slow0);
+    const pg_parents_info o = pg_build_parents(N, R, K, child, rows_form != 0, L, cur, rank_chunk0, ev_slow0);
     meta[0] = n_adp; meta[1] = (int32_t)o.n_chunks; meta[2] = (int32_t)o.max_chunks; meta[3] = o.n_slow; meta[4] = o.n_par;
     meta[5] = (int32_t)L.cap;
     for (int r = 0; r <= R; ++r) {

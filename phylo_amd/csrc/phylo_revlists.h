@@ -95,6 +95,17 @@ inline int32_t pg_build_adopters(int R, int K, const int64_t* anc, const pg_list
     return n_adp;
 }
 
+// Bit 2 of slow_flag for every node somebody adopted (r - 1, anc[r-1][k]): what pg_build_parents needs of the adopters when the early
+// pg_nodes_free has skipped the adopted nodes -- one pass over the ancestors, so the parents' lists can be built (and the launch that
+// needs them started) before the adopters' counting sorts.
+inline void pg_mark_adopted(int R, int K, const int64_t* anc, const pg_lists& L) {
+    for (int r = 1; r < R; ++r) {
+        const int64_t* a = anc + (size_t)(r - 1) * K;
+        int32_t* f = L.slow_flag + (size_t)(r - 1) * K;
+        for (int k = 0; k < K; ++k) f[a[k]] |= 4;
+    }
+}
+
 struct pg_parents_info {
     size_t n_chunks, max_chunks;       // chunks in all, most chunks of one rank event
     int32_t n_slow, n_par;             // flagged nodes, parent entries
@@ -109,8 +120,8 @@ struct pg_parents_info {
 // within the rank event (rank_chunk0); nodes with parents (bit 0), look-ahead entries (bit 1, set by the caller) or -- after the
 // early pg_nodes_free -- adopters (bit 2) are flagged ((index in slow_idx) << 3 | bits) and listed by rank event (ev_slow0) for
 // pg_nodes_rows; all the others: pg_nodes_free.  A parent that goes through pg_nodes_free never stores its adjoint row: its
-// entries carry PG_FREE_PARENT (rows form only).  Needs pg_build_adopters' ad_off when early_free.
-inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* child, bool early_free, bool rows_form, const pg_lists& L,
+// entries carry PG_FREE_PARENT (rows form only).  After the early pg_nodes_free the caller runs pg_mark_adopted first.
+inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* child, bool rows_form, const pg_lists& L,
                                         std::vector<int32_t>& cur, std::vector<int32_t>& rank_chunk0, std::vector<int32_t>& ev_slow0) {
     const size_t nn = (size_t)R * K;
     // (leaf or internal child is a coin toss in the later rank events: no branch on it -- a leaf counts into one of 64 dummies in
@@ -129,15 +140,12 @@ inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* chil
     for (int r = 0; r < R; ++r) {
         rank_chunk0[r] = (int32_t)n_chunks;
         ev_slow0[r] = ns;
-        const int32_t* adn = r + 1 < R ? L.ad_off + (size_t)(r + 1) * (K + 1) : nullptr;
         for (int k = 0; k < K; ++k) {
             const size_t x = (size_t)r * K + k;
             const int32_t np = L.par_off[x + 1];         // still the count: the offsets are written behind the read position
             L.par_off[x] = run;
-            int32_t f = L.slow_flag[x];                  // (bit 1 set by the caller: look-ahead entries)
-            if (np) f |= 1;
-            // the early launch skipped every marked (= adopted) node: those without parents join the few flagged ones
-            if (early_free && adn && adn[k + 1] > adn[k]) f |= 4;
+            int32_t f = L.slow_flag[x];                  // (set by the caller: bit 1 look-ahead entries, bit 2 adopted -- pg_mark_adopted:
+            if (np) f |= 1;                              //  the early launch skipped those; without parents they join the flagged ones)
             L.heavy[x] = -1;
             if (np > PG_PCHUNK) {
                 L.heavy[x] = (int32_t)(n_chunks - rank_chunk0[r]);
