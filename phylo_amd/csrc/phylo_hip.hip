@@ -1715,16 +1715,16 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
     if (early_free) pg_mark_adopted(R, K, anc, L);
     auto parents_block = [&]() -> int {
     // ---- parents, heavy nodes' chunks, flagged nodes by rank event (pg_build_parents)
-    pinfo = pg_build_parents(N, R, K, child, rows_form, L, cur, rank_chunk0, ev_slow0);
+    pinfo = pg_build_parents(N, R, K, child, rows_form, early_free, L, cur, rank_chunk0, ev_slow0);
     max_chunks = pinfo.max_chunks; n_chunks = pinfo.n_chunks;
     {
         const int32_t ns = pinfo.n_slow;
         void* cpart = nullptr;
         // rows form: the chunk sums of ALL rank events are produced by one launch (free parents only: nothing of the chain is
         // needed for them), so the buffer holds every chunk; else one rank event's at a time
-        CHK(scratch_get(c, 5, (rows_form ? n_chunks : max_chunks) * (size_t)S * 4 * 8, &cpart));
+        CHK(scratch_get(c, 5, (early_free ? n_chunks : max_chunks) * (size_t)S * 4 * 8, &cpart));
         g.cpart = (double*)cpart;
-        g.chunks_free_only = rows_form ? 1 : 0;
+        g.chunks_free_only = early_free ? 1 : 0;
         g.TS = cdiv(S, 256);
         {
             void* fp = nullptr;
@@ -1748,11 +1748,10 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         CHK(launch_check(c, "pg_copy_words"));
         if (two) HIPCHK(c, hipEventRecord(c->ev_gup, sB));
     }
-    if (rows_form && n_chunks > 0) {
+    if (early_free && n_chunks > 0) {
         // The parents of a heavy node are nearly all nodes nobody merged again: their share of the node's adjoint needs their
-        // alpha and nothing else -- omega itself after the early pg_nodes_free, else the finished coefficients.  ONE launch sums
+        // alpha = omega and nothing else.  ONE launch sums
         // them for the chunks of all rank events; the chain below is then pg_nodes_rows alone, which adds the flagged parents.
-        if (two && !early_free) HIPCHK(c, hipStreamWaitEvent(sB, c->ev_coeff[0], 0));
         const size_t rowlen = (size_t)S * 4;
         for (size_t cbeg = 0; cbeg < n_chunks; cbeg += 65535) {
             const size_t cn = n_chunks - cbeg < 65535 ? n_chunks - cbeg : 65535;
@@ -1911,7 +1910,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
             CHK(launch_check(c, "pg_twist_xsum"));
             tw_launches += 2;
         }
-        const int nch = rows_form ? 0 : rank_chunk0[r + 1] - rank_chunk0[r];   // (rows form: summed above, all rank events at once)
+        const int nch = early_free ? 0 : rank_chunk0[r + 1] - rank_chunk0[r];   // (after the early pg_nodes_free: summed above, all rank events at once)
         if (nch > 0) {
             hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), nch), dim3(256), 0, sB, g, (int)rank_chunk0[r]);
             CHK(launch_check(c, "pg_parent_chunks"));
@@ -1920,7 +1919,7 @@ int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double*
         if (rows_form) {
             const int nslow = ev_slow0[r + 1] - ev_slow0[r];
             if (nslow > 0) {
-                hipLaunchKernelGGL(pg_nodes_rows, dim3(nslow, g.TS), dim3(256), 0, sB, g, r, (int)ev_slow0[r], (int)rank_chunk0[r]);
+                hipLaunchKernelGGL(pg_nodes_rows, dim3(nslow, g.TS), dim3(256), 0, sB, g, r, (int)ev_slow0[r], early_free ? (int)rank_chunk0[r] : 0);
                 ++node_launches;
             }
         } else {
@@ -1988,7 +1987,7 @@ int phylo_debug_reverse_lists(int N, int K, const int64_t* ancestors, const int3
         if (lookahead_nodes[i] < N || lookahead_nodes[i] >= N + R * K) return fail(nullptr, PHYLO_EINVAL, "phylo_debug_reverse_lists: node id out of range");
         L.slow_flag[lookahead_nodes[i] - N] |= 2;
     }
-    const pg_parents_info o = pg_build_parents(N, R, K, child, rows_form != 0, L, cur, rank_chunk0, ev_slow0);
+    const pg_parents_info o = pg_build_parents(N, R, K, child, rows_form != 0, rows_form != 0 && early_free != 0, L, cur, rank_chunk0, ev_slow0);
     meta[0] = n_adp; meta[1] = (int32_t)o.n_chunks; meta[2] = (int32_t)o.max_chunks; meta[3] = o.n_slow; meta[4] = o.n_par;
     meta[5] = (int32_t)L.cap;
     for (int r = 0; r <= R; ++r) {

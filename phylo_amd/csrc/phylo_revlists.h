@@ -121,7 +121,7 @@ struct pg_parents_info {
 // early pg_nodes_free -- adopters (bit 2) are flagged ((index in slow_idx) << 3 | bits) and listed by rank event (ev_slow0) for
 // pg_nodes_rows; all the others: pg_nodes_free.  A parent that goes through pg_nodes_free never stores its adjoint row: its
 // entries carry PG_FREE_PARENT (rows form only).  After the early pg_nodes_free the caller runs pg_mark_adopted first.
-inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* child, bool rows_form, const pg_lists& L,
+inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* child, bool rows_form, bool tail_flagged, const pg_lists& L,
                                         std::vector<int32_t>& cur, std::vector<int32_t>& rank_chunk0, std::vector<int32_t>& ev_slow0) {
     const size_t nn = (size_t)R * K;
     // (leaf or internal child is a coin toss in the later rank events: no branch on it -- a leaf counts into one of 64 dummies in
@@ -170,7 +170,8 @@ inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* chil
     // scatter without a branch on leaf / internal (masks, not ?: -- the compiler made a branch of that, mispredicted every other
     // time in the later rank events): a leaf child advances one of 64 dummy cursors and writes into the tail of par_idx,
     // which is never used (the 2 K children of rank event 0 are all leaves).
-    // Rows form: the entries of FREE parents (no flag: their adjoint is recomputed, nothing of the chain is needed) fill a child's
+    // tail_flagged (the plain reverse pass after the early pg_nodes_free): the entries of FREE parents (no flag: their adjoint is
+    // recomputed from omega, nothing of the chain is needed) fill a child's
     // list from the front, ascending; the few entries of flagged parents from the back, so the list ends with them in descending
     // order -- pg_parent_chunks_all sums the free ones of every rank event in one launch, pg_nodes_rows walks the tail.
     cur.resize(2 * (nn + 64));
@@ -190,7 +191,7 @@ inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* chil
         const int32_t lane = (int32_t)(e & 63);
         const int32_t ci = ((ch - N) & in) | (((int32_t)nn + lane) & ~in);
         const int32_t fl = L.slow_flag[e >> 1] != 0;         // the parent is a flagged node
-        const int32_t tob = fl & (rows_form ? 1 : 0);        // 1: from the back
+        const int32_t tob = fl & (tail_flagged ? 1 : 0);     // 1: from the back
         int32_t* cp = front + (ptrdiff_t)tob * rowlen + ci;
         const int32_t pos = *cp;
         *cp = pos + 1 - 2 * tob;

@@ -91,7 +91,7 @@ def test_lists_match_restatement(N, K, survivors, early, rows, seed):
     assert po[0] == 0 and po[nn] == out["n_par"] == sum(len(p) for p in parents)
     for x in range(nn):
         got = out["par_idx"][po[x]:po[x + 1]]
-        if rows:       # entries of free parents first, ascending; those of flagged parents behind them, descending
+        if rows and early:   # entries of free parents first, ascending; those of flagged parents behind them, descending
             free = [e for e in parents[x] if flags[e >> 1] == 0]
             slow = [e for e in parents[x] if flags[e >> 1] != 0]
             want = free + slow[::-1]
