@@ -411,7 +411,8 @@ __device__ __forceinline__ double pg_parent_quad(const pg_args& a, size_t soff, 
     return xb;
 }
 
-// grid (groups of 16 PG_CSTEPS sites, chunks of this rank event): cpart[chunk][s] = sum of the chunk's parent contributions.  The chunk's
+// grid (groups of 16 PG_CSTEPS sites, chunks -- of rank event chunk0's range, or with chunks_free_only of ALL rank events, chunk0
+// = the first of the launch): cpart[chunk][s] = sum of the chunk's parent contributions (free parents' only with chunks_free_only).  The chunk's
 // (up to PG_HCHUNK = 4 PG_PCHUNK) parents are staged at once and each of the four waves gathers its own PG_PCHUNK of them for the
 // same 16 PG_CSTEPS sites (all sibling rows of the steps in flight together); the four partial sums are added in wave order.
 // (One wave after the other over 64 sites -- the first version -- paid a staging and a gather latency per PG_PCHUNK parents:
