@@ -174,11 +174,13 @@ inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* chil
     // recomputed from omega, nothing of the chain is needed) fill a child's
     // list from the front, ascending; the few entries of flagged parents from the back, so the list ends with them in descending
     // order -- pg_parent_chunks_all sums the free ones of every rank event in one launch, pg_nodes_rows walks the tail.
-    cur.resize(2 * (nn + 64));
+    cur.resize((tail_flagged ? 2 : 1) * (nn + 64));
     int32_t* front = cur.data();
-    int32_t* back = front + nn + 64;
     memcpy(front, L.par_off, nn * 4);
-    for (size_t x = 0; x < nn; ++x) back[x] = L.par_off[x + 1] - 1;
+    if (tail_flagged) {                                     // (the cursors from the back: the row behind the front cursors)
+        int32_t* back = front + nn + 64;
+        for (size_t x = 0; x < nn; ++x) back[x] = L.par_off[x + 1] - 1;
+    }
     const int32_t free_bit = rows_form ? PG_FREE_PARENT : 0;
     const int32_t tail = (int32_t)(2 * nn) - 1;
     int32_t tmask = 1;                                      // dummy slots: the last min(64, 2 K rounded down to a power of two)
