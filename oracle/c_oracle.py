@@ -46,6 +46,15 @@ def set_threads(n):
     lib().ora_set_threads(int(n))
 
 
+def set_site_tile(T):
+    """contract v5: site tile of the canonical sum over sites (0 = the policy of ora_site_tile)"""
+    lib().ora_set_site_tile(C.c_int(int(T)))
+
+
+def site_tile(S):
+    return int(lib().ora_get_site_tile(C.c_long(int(S))))
+
+
 def math_probe(op, x, y=None):
     x = _c(x)
     y = _c(x if y is None else y)

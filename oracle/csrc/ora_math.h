@@ -257,11 +257,42 @@ static inline double ora_lp_finish(const ora_lp* a) {
     return ((ora_log(a->p) + dE * 1.90821492927058770002e-10) + dE * 6.93147180369123816490e-01) + a->extra;
 }
 
-/* canonical sum of logs over sites: 256 log-product columns (site s multiplies into column s mod 256, in
- * increasing s), each finished to a double, then the same tree as the canonical sum below. */
-typedef struct { ora_lp col[256]; } ora_canon_lp;
-static inline void ora_canon_lp_init(ora_canon_lp* c) { for (int i = 0; i < 256; ++i) ora_lp_init(&c->col[i]); }
-static inline void ora_canon_lp_mul(ora_canon_lp* c, long s, double x) { ora_lp_mul(&c->col[s & 255], x); }
+/* canonical sum of logs over sites (contract v5): the S sites are cut into TILES of T sites
+ * (T = ora_site_tile(S), a multiple of 64); inside a tile site s multiplies into log-product column (s - tile start) mod 64,
+ * in increasing s; each column is finished to a double, the 64 column values are added by the adjacent-pair tree, and the
+ * tile values are added left to right.  (Until contract v4: one tile, 256 columns.) */
+static int ora_tile_override = 0;                       /* tests / experiments: ora_set_site_tile */
+static inline int ora_site_tile(long S) { (void)S; return ora_tile_override > 0 ? ora_tile_override : 2048; }
+static inline double ora_tree64(double* v) {
+    for (int st = 1; st < 64; st <<= 1)
+        for (int i = 0; i < 64; i += 2 * st) v[i] = v[i] + v[i + st];
+    return v[0];
+}
+typedef struct { ora_lp col[64]; long T, tile; int ntiles; double total; } ora_canon_lp;
+static inline void ora_canon_lp_init(ora_canon_lp* c, long S) {
+    for (int i = 0; i < 64; ++i) ora_lp_init(&c->col[i]);
+    c->T = ora_site_tile(S); c->tile = 0; c->ntiles = 0; c->total = 0.0;
+}
+static inline void ora_canon_lp_close_tile(ora_canon_lp* c) {
+    double v[64];
+    for (int i = 0; i < 64; ++i) { v[i] = ora_lp_finish(&c->col[i]); ora_lp_init(&c->col[i]); }
+    const double t = ora_tree64(v);
+    c->total = c->ntiles ? c->total + t : t;
+    ++c->ntiles;
+}
+/* sites must arrive in increasing s */
+static inline void ora_canon_lp_mul(ora_canon_lp* c, long s, double x) {
+    while (s >= (c->tile + 1) * c->T) { ora_canon_lp_close_tile(c); ++c->tile; }
+    ora_lp_mul(&c->col[(s - c->tile * c->T) & 63], x);
+}
+static inline double ora_canon_lp_total(ora_canon_lp* c) { ora_canon_lp_close_tile(c); return c->total; }
+
+/* a sum of at most 64 terms in the site-sum tree (contract v3: the 25 code-pair terms of a leaf-leaf look-ahead row):
+ * term i sits in column i of ONE tile, every other column is 0 */
+typedef struct { double col[64]; } ora_canon64;
+static inline void ora_canon64_init(ora_canon64* c) { for (int i = 0; i < 64; ++i) c->col[i] = 0.0; }
+static inline void ora_canon64_add(ora_canon64* c, int i, double v) { c->col[i] = c->col[i] + v; }
+static inline double ora_canon64_total(ora_canon64* c) { return ora_tree64(c->col); }
 
 /* canonical sum: 256 columns (element s goes to column s mod 256, added in increasing s), then an
  * adjacent-pair tree inside each group of 64 columns, then the four groups left to right. */
@@ -273,10 +304,5 @@ static inline double ora_canon_total(ora_canon* c) {
         for (int st = 1; st < 64; st <<= 1)
             for (int i = 0; i < 64; i += 2 * st) c->col[g * 64 + i] = c->col[g * 64 + i] + c->col[g * 64 + i + st];
     return ((c->col[0] + c->col[64]) + c->col[128]) + c->col[192];
-}
-static inline double ora_canon_lp_total(ora_canon_lp* c) {
-    ora_canon t;
-    for (int i = 0; i < 256; ++i) t.col[i] = ora_lp_finish(&c->col[i]);
-    return ora_canon_total(&t);
 }
 #endif

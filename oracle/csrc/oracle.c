@@ -35,6 +35,10 @@ int ora_num_threads(void) {
 #endif
 }
 
+/* contract v5: the site tile of the canonical sum over sites.  0 restores the policy ora_site_tile(S). */
+void ora_set_site_tile(int T) { ora_tile_override = T > 0 ? T : 0; }
+int ora_get_site_tile(long S) { return ora_site_tile(S); }
+
 void ora_set_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);
@@ -92,7 +96,7 @@ static inline double site_lik(const double* pi, const double* x) {
 /* sum_s log(pi . x[s]) in the canonical order */
 static double row_loglik(const double* pi, const double* x, int S) {
     ora_canon_lp c;
-    ora_canon_lp_init(&c);
+    ora_canon_lp_init(&c, S);
     for (int s = 0; s < S; ++s) ora_canon_lp_mul(&c, s, site_lik(pi, x + (size_t)s * 4));
     return ora_canon_lp_total(&c);
 }
@@ -354,7 +358,7 @@ int ora_sweep(const double* genome /*[N][S][4]*/, const double* Q, const double*
 /* Leaf codes of the reference's encoding (runner.py:83-96): 0..3 one-hot state, 4 all-ones.  Returns 1 when every
  * leaf row is one of them.  For such alignments the look-ahead potential of a leaf-leaf pair is priced by state
  * pair: sum_s log f(c_l[s], c_r[s]) = sum over the 25 code pairs of count * log f (contract v3);
- * term of code pair c goes to canonical column c. */
+ * term of code pair c goes to column c of a single 64-column tile. */
 static int leaf_codes(const double* genome, size_t rows, uint8_t* codes) {
     for (size_t i = 0; i < rows; ++i) {
         const double* x = genome + i * 4;
@@ -466,17 +470,17 @@ int ora_sweep_twisted(const double* genome, const double* Q, const double* pi, c
                         double merged_ll;
                         if (coded && ls[r1] >= 0 && ls[r2] >= 0) {          /* leaf-leaf pair: 25 code pairs */
                             const uint32_t* h = hist + ((size_t)ls[r1] * N + ls[r2]) * 25;
-                            ora_canon cs;
-                            ora_canon_init(&cs);
+                            ora_canon64 cs;
+                            ora_canon64_init(&cs);
                             for (int cp = 0; cp < 25; ++cp) {
                                 if (!h[cp]) continue;
                                 double Lv[4], Rv[4], o[4];
                                 code_row(cp / 5, Lv);
                                 code_row(cp % 5, Rv);
                                 merge_site(Lv, Rv, Pl, Pr, o);
-                                ora_canon_add(&cs, cp, (double)h[cp] * ora_log(site_lik(pi, o)));
+                                ora_canon64_add(&cs, cp, (double)h[cp] * ora_log(site_lik(pi, o)));
                             }
-                            merged_ll = ora_canon_total(&cs);
+                            merged_ll = ora_canon64_total(&cs);
                         } else if (coded && ((ls[r1] >= 0) != (ls[r2] >= 0))) {
                             /* coded leaf x internal root (contract v4): the site likelihood depends on the leaf only through
                              * its code c, lik[s] = X[s] . v_c with v_c[i] = sum_j P_int[i][j] (pi_j (leaf_c . P_leaf)[j]) */
@@ -501,7 +505,7 @@ int ora_sweep_twisted(const double* genome, const double* Q, const double* pi, c
                                 }
                             }
                             ora_canon_lp cl;
-                            ora_canon_lp_init(&cl);
+                            ora_canon_lp_init(&cl, S);
                             for (int s = 0; s < S; ++s) {
                                 const double* x = X + (size_t)s * 4;
                                 const double* vc = v[cd[s]];

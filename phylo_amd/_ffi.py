@@ -30,6 +30,7 @@ EXPORTS = [
     "phylo_sweep_async", "phylo_sweep_batch_async", "phylo_sweep_batch_begin", "phylo_sweep_fetch_logz", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_step_a", "phylo_sweep_step_group", "phylo_sweep_finish", "phylo_sweep_fetch",
     "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
     "phylo_math_probe", "phylo_debug_stamps", "phylo_debug_reverse_lists",
+    "phylo_site_tile", "phylo_set_site_tile", "phylo_get_site_tile",
     "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_allgather", "phylo_comm_max", "phylo_comm_barrier",
 ]
 
@@ -145,6 +146,13 @@ class Context:
         self.close()
 
     # ---- state
+    def set_site_tile(self, T):
+        """contract v5: sites per tile of the canonical sum over sites (0 = the default phylo_site_tile(S))"""
+        self._check(self._lib.phylo_set_site_tile(self._h, C.c_int(int(T))))
+
+    def site_tile(self):
+        return int(self._lib.phylo_get_site_tile(self._h))
+
     def set_leaves(self, genome_NxSxA):
         g = _f64(genome_NxSxA)
         if g.shape != (self.N, self.S, self.A):

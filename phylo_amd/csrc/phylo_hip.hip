@@ -107,6 +107,9 @@ struct phylo_ctx {
     double *d_bl = nullptr, *d_br = nullptr, *d_Pmat = nullptr;   // [(N-1)][Kloc](x32)
     double *d_logw = nullptr, *d_ll = nullptr;                    // [(N-1)][K] (global columns)
     double* d_aux = nullptr;             // [Kloc][PK_AUX]
+    int tile_override = 0;               // PHYLO_SITE_TILE / phylo_set_site_tile (0: the policy pm_site_tile)
+    int site_tile = 0, ntiles = 1;       // contract v5: sites per tile of the canonical sum over sites (multiple of 64), ceil(S / tile)
+    double* d_tilev = nullptr;           // [Kloc][ntiles] tile values of the merge (rows longer than one tile)
     double* d_lse = nullptr;             // [PK_MAX_GROUPS][N-1 + total]; group 0 only unless sweeps are batched
     uint64_t* d_group_seeds = nullptr;   // [PK_MAX_GROUPS]
     // root tables, two planes each, carved from ONE slab (so that peers map it with one handle):
@@ -297,6 +300,8 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_rdraw = c->d_pctr = nullptr;
     c->pctr_base = 0;
     c->pctr_Wg = 0;
+    if (c->d_tilev) (void)hipFree(c->d_tilev);
+    c->d_tilev = nullptr;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse, c->d_group_seeds,
                     c->d_tables, (void*)c->d_tab_ptrs, c->d_child, c->d_merges, c->d_anc,
                     c->d_cdf[0], c->d_cdf[1], c->d_counter, (void*)c->d_pool_ptrs, c->d_mark, c->d_sync};
@@ -328,6 +333,7 @@ int alloc_sweep_state(phylo_ctx* c) {
     CHK(dalloc(c, &c->d_logw, R * K));
     CHK(dalloc(c, &c->d_ll, R * K));
     CHK(dalloc(c, &c->d_aux, Kl * PK_AUX));
+    if (c->ntiles > 1) CHK(dalloc(c, &c->d_tilev, Kl * (size_t)c->ntiles));
     CHK(dalloc(c, &c->d_lse, (R + 1) * PK_MAX_GROUPS));
     CHK(dalloc(c, &c->d_group_seeds, PK_MAX_GROUPS));
     CHK(dalloc(c, &c->d_tables, 32 * K * N));
@@ -454,9 +460,12 @@ int wait_event_spin(phylo_ctx* c, hipEvent_t ev) {
     return PHYLO_OK;
 }
 
+// site tile of an op-level call on rows of S sites (the context's own S has c->site_tile)
+int tile_for(const phylo_ctx* c, int S) { return c->tile_override ? c->tile_override : pm_site_tile(S); }
+
 int refresh_leaf_ll(phylo_ctx* c) {
     if (!(c->have_leaves && c->have_model && c->state_ready)) return PHYLO_OK;
-    hipLaunchKernelGGL(pk_row_loglik, dim3(c->N), dim3(PK_COLS), 0, c->stream, c->d_leaves, c->d_pi, c->S,
+    hipLaunchKernelGGL(pk_row_loglik, dim3(c->N), dim3(64), 0, c->stream, c->d_leaves, c->d_pi, c->S, c->site_tile,
                        c->d_nodell);
     return launch_check(c, "pk_row_loglik(leaves)");
 }
@@ -498,6 +507,14 @@ int phylo_create(const int* device_ids, int n_gpus, int K, int N, int S, int A, 
     c->Kloc = K; c->k0 = 0;
     c->flags = flags;
     c->env.read();
+    {   // contract v5: the site tile is part of the arithmetic contract (the oracle takes the same value)
+        const char* t = getenv("PHYLO_SITE_TILE");
+        int T = t ? atoi(t) : pm_site_tile(S);
+        if (T < 64 || (T & 63)) { delete c; return fail(nullptr, PHYLO_EINVAL, "PHYLO_SITE_TILE must be a positive multiple of 64 (got %d)", T); }
+        c->tile_override = t ? T : 0;
+        c->site_tile = T;
+        c->ntiles = (S + T - 1) / T;
+    }
     int rc = PHYLO_OK;
     do {
         if ((rc = bind(c)) != PHYLO_OK) break;
@@ -560,6 +577,24 @@ int phylo_destroy(phylo_ctx* c) {
     if (c->h_leaves_p) (void)hipHostFree(c->h_leaves_p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return PHYLO_OK;
+}
+
+int phylo_site_tile(int S) { return pm_site_tile(S); }
+
+int phylo_get_site_tile(const phylo_ctx* c) { return c ? c->site_tile : 0; }
+
+int phylo_set_site_tile(phylo_ctx* c, int T) {
+    CHK(bind(c));
+    if (T < 0 || (T & 63)) return fail(c, PHYLO_EINVAL, "the site tile must be a positive multiple of 64, or 0 for the default (got %d)", T);
+    if (c->comm.transport != 0) return fail(c, PHYLO_ESTATE, "phylo_set_site_tile must precede phylo_comm_init (peers map the sweep state)");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tile_override = T;
+    c->site_tile = T ? T : pm_site_tile(c->S);
+    c->ntiles = (c->S + c->site_tile - 1) / c->site_tile;
+    free_sweep_state(c);                                   // tile values, leaf log-likelihoods: rebuilt by the next sweep
+    c->state_ready = false;
+    c->swept = false;
     return PHYLO_OK;
 }
 
@@ -710,7 +745,7 @@ int phylo_forest_loglik(phylo_ctx* c, const double* core, const int32_t* record,
     if (rows) {
         HIPCHK(c, hipMemcpyAsync(dcore, core, rows * S * 4 * 8, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(drec, record, rows * 4, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(pk_row_loglik, dim3((unsigned)rows), dim3(PK_COLS), 0, c->stream, (const double*)dcore, c->d_pi, S,
+        hipLaunchKernelGGL(pk_row_loglik, dim3((unsigned)rows), dim3(64), 0, c->stream, (const double*)dcore, c->d_pi, S, tile_for(c, S),
                            (double*)drow);
         CHK(launch_check(c, "pk_row_loglik"));
     }
@@ -779,7 +814,7 @@ int phylo_tree_loglik(phylo_ctx* c, int n_nodes, int n_leaves, int S, const int3
         CHK(launch_check(c, "pk_tree_prune"));
     }
     const double* droot = (const double*)dnodes + (size_t)root * S * 4;
-    hipLaunchKernelGGL(pk_row_loglik, dim3(1), dim3(PK_COLS), 0, c->stream, droot, (const double*)dpr, S, (double*)dout);
+    hipLaunchKernelGGL(pk_row_loglik, dim3(1), dim3(64), 0, c->stream, droot, (const double*)dpr, S, tile_for(c, S), (double*)dout);
     CHK(launch_check(c, "pk_row_loglik"));
     HIPCHK(c, hipMemcpyAsync(out_loglik, dout, 8, hipMemcpyDeviceToHost, c->stream));
     if (root_data) HIPCHK(c, hipMemcpyAsync(root_data, droot, (size_t)S * 4 * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1057,6 +1092,7 @@ static int sweep_persistent(phylo_ctx* c, uint64_t seed, uint32_t flags, const u
     }
     pp_args a{};
     a.N = N; a.S = S; a.K = K; a.Kg = Kg; a.G = G; a.R = R; a.Wg = Wg; a.m = m;
+    a.T = c->site_tile;
     a.seed = seed; a.flags = flags; a.jc = c->jc;
     if (G > 1) {
         HIPCHK(c, hipMemcpyAsync(c->d_group_seeds, group_seeds, (size_t)G * 8, hipMemcpyHostToDevice, c->stream));
@@ -1195,6 +1231,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
         b.merges = c->d_merges; b.ancestors = c->d_anc;
         b.child = c->d_child + (size_t)r * Kl * 2; b.aux = c->d_aux;
         b.lazy = lazy ? 1 : 0; b.mark = c->d_mark; b.child_all = c->d_child; b.Pmat_all = c->d_Pmat;
+        b.T = c->site_tile; b.ntiles = c->ntiles; b.tilev = c->d_tilev;
         if (twist) {
             pk_twist_args ta{};
             ta.a = b;
@@ -1300,14 +1337,20 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                 CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
             }
         }
-        const bool nostore = (b.lazy || b.no_store) && !c->env.merge_pair_form;   // row-per-thread form when nothing is stored
+        const bool nostore = (b.lazy || b.no_store) && !c->env.merge_pair_form;   // row-per-lane form when nothing is stored
+        const dim3 mgrid((unsigned)((size_t)Kl * c->ntiles));                      // one wave per (particle, site tile)
         if (timek && !twist) {  // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
-            if (nostore) hipExtLaunchKernelGGL(pk_rank_merge_nostore, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
-            else hipExtLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
+            if (nostore) hipExtLaunchKernelGGL(pk_rank_merge_nostore, mgrid, dim3(64), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
+            else hipExtLaunchKernelGGL(pk_rank_merge, mgrid, dim3(64), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
         } else if (nostore) {
-            hipLaunchKernelGGL(pk_rank_merge_nostore, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
+            hipLaunchKernelGGL(pk_rank_merge_nostore, mgrid, dim3(64), 0, c->stream, b);
         } else {
-            hipLaunchKernelGGL(pk_rank_merge, dim3(Kl), dim3(PK_COLS), 0, c->stream, b);
+            hipLaunchKernelGGL(pk_rank_merge, mgrid, dim3(64), 0, c->stream, b);
+        }
+        if (c->ntiles > 1) {    // rows longer than one tile: tile values left to right, then the particle's weight terms
+            CHK(launch_check(c, "pk_rank_merge"));
+            hipLaunchKernelGGL(pk_tile_epilogue, dim3(cdiv(Kl, 256)), dim3(256), 0, c->stream, b);
+            ++launches;
         }
         CHK(launch_check(c, "pk_rank_merge"));
         ++launches;

@@ -15,11 +15,10 @@
 enum { AUX_SUM_REM = 0, AUX_FPRIOR, AUX_LPRIOR, AUX_RPRIOR, AUX_LL_TILDE, AUX_PAREN, AUX_LOGV, AUX_Q };
 
 // ------------------------------------------------------------------------------------------------
-// canonical sum over sites: element s belongs to column s mod 256; a column's value is the log of the
-// running product of its elements in increasing s (pm_lp); the 256 column values are then added by the tree
-// below.  Canonical sum over the 256 columns of a workgroup: adjacent-pair tree inside each 64-lane wave
-// (xor butterfly 1,2,...,32: a+b == b+a bitwise, so every lane ends with the same value), then the four
-// wave totals left to right.  oracle/csrc/oracle.c mirrors exactly this tree.
+// Canonical sum over 256 columns of a workgroup (the sum over PARTICLES of the resampling weights: element k
+// belongs to column k mod 256): adjacent-pair tree inside each 64-lane wave (xor butterfly 1,2,...,32:
+// a+b == b+a bitwise, so every lane ends with the same value), then the four wave totals left to right.
+// oracle/csrc/oracle.c mirrors exactly this tree.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double pk_block_canon_sum(double col, double* sh4) {
 #pragma unroll
@@ -28,6 +27,36 @@ __device__ __forceinline__ double pk_block_canon_sum(double col, double* sh4) {
     if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = col;
     __syncthreads();
     return ((sh4[0] + sh4[1]) + sh4[2]) + sh4[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Canonical sum over SITES (contract v5, phylo_math.h): one wave owns a (row, tile); lane l holds the finished column l
+// (the log of the running product of sites tile start + l + 64 j, pm_lp); the 64 columns are added by the adjacent-pair
+// tree below, tile values left to right.  Levels 1..8 are DPP moves inside a row of 16 lanes (after levels 1 and 2 a quad
+// holds one value, so the mirrored partner of level 4 / 8 holds exactly the value of the xor partner); the four row totals
+// are read by lane and added as (r0 + r1) + (r2 + r3).  a + b is commutative bit for bit: the xor butterfly's result without
+// six dependent trips through the LDS crossbar.  Wave-uniform result.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double pk_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pk_readlane(double v, int l) {      // l wave-uniform
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pk_wave_tree_sum(double v) {
+    v = v + pk_dpp<0xB1>(v);          // quad_perm [1,0,3,2]: xor 1
+    v = v + pk_dpp<0x4E>(v);          // quad_perm [2,3,0,1]: xor 2
+    v = v + pk_dpp<0x141>(v);         // row_half_mirror: the other quad of my 8
+    v = v + pk_dpp<0x140>(v);         // row_mirror: the other 8 of my row
+    const double r0 = pk_readlane(v, 0), r1 = pk_readlane(v, 16), r2 = pk_readlane(v, 32), r3 = pk_readlane(v, 48);
+    return (r0 + r1) + (r2 + r3);
 }
 
 // Partial-likelihood rows always live in global memory (leaves, this rank's pool or a peer's mapped pool), but
@@ -169,20 +198,24 @@ __global__ __launch_bounds__(64) void pk_sweep_prologue(const pk_prologue_args p
 }
 
 // ------------------------------------------------------------------------------------------------
-// canonical sum_s log(pi . x[s]) of `rows` vectors [S,4]; one workgroup per row.
+// canonical sum_s log(pi . x[s]) of `rows` vectors [S,4]; one wave per row, its tiles (T sites) one after the other.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PK_COLS) void pk_row_loglik(const double* __restrict__ x, const double* __restrict__ pi4,
-                                                          int S, double* __restrict__ out) {
-    __shared__ double sh4[4];
+__global__ __launch_bounds__(64) void pk_row_loglik(const double* __restrict__ x, const double* __restrict__ pi4,
+                                                     int S, int T, double* __restrict__ out) {
     const double* row = x + (size_t)blockIdx.x * S * 4;
     double pi[4] = {pi4[0], pi4[1], pi4[2], pi4[3]};
-    pm_lp col = pm_lp_init();
-    for (int s = threadIdx.x; s < S; s += PK_COLS) {
-        double v[4];
-        pk_load4(row + (size_t)s * 4, v);
-        pm_lp_mul(col, pk_site_lik(pi, v));
+    double tot = 0.0;
+    for (int s0 = 0; s0 < S; s0 += T) {
+        const int s1 = s0 + T < S ? s0 + T : S;
+        pm_lp col = pm_lp_init();
+        for (int s = s0 + threadIdx.x; s < s1; s += 64) {
+            double v[4];
+            pk_load4(row + (size_t)s * 4, v);
+            pm_lp_mul(col, pk_site_lik(pi, v));
+        }
+        const double t = pk_wave_tree_sum(pm_lp_finish(col));
+        tot = s0 ? tot + t : t;
     }
-    const double tot = pk_block_canon_sum(pm_lp_finish(col), sh4);
     if (threadIdx.x == 0) out[blockIdx.x] = tot;
 }
 
@@ -551,6 +584,10 @@ struct pk_rank_args {
     const uint64_t* group_seeds;                          // [G] or NULL (use `seed`)
     int no_store;                                         // the merge does not store its node (last rank event: never read again)
     const unsigned long long* rdraw;                      // [K] 64-bit resampling draws of this rank event (pk_rank_book_mat)
+    // contract v5: site tile T (multiple of 64), ntiles = ceil(S / T).  With more than one tile a merge wave leaves its tile's
+    // value in tilev[k][tile] and pk_tile_epilogue adds them left to right and finishes the particle.
+    int T, ntiles;
+    double* tilev;                                        // [Kloc][ntiles] or NULL (ntiles == 1)
 };
 
 // LDS carve of the bookkeeping prologue (arrays of length N rounded up to a multiple of 4)
@@ -1198,16 +1235,16 @@ __global__ __launch_bounds__(PK_COLS) void pk_rank_scan_book(const pk_rank_args 
 }
 
 // ------------------------------------------------------------------------------------------------
-// The Felsenstein merge of one rank event, one workgroup (256 threads) per local particle.
+// The Felsenstein merge of one rank event, one WAVE per (local particle, site tile); grid = Kloc x ntiles workgroups of 64.
 //   k2: the new node's partial likelihoods, out[s,:] = (L[s,:] P_l) * (R[s,:] P_r)      (vcsmc.py:185-187)
 //   k3: sum_s log(pi . out[s,:]) in the canonical order                                  (vcsmc.py:240-242)
 //   k8: log_likelihood_r and log w_r                                                     (vcsmc.py:376-392)
-// Half-row form: a lane PAIR owns a site.  Lane parity h loads the 16 bytes holding states 2h, 2h+1 of each
-// child (so a wave reads 1 KiB contiguous per instruction from the [K x S x 4] tensor), completes the rows
+// Half-row form (the form that STORES the node): a lane PAIR owns a site.  Lane parity h loads the 16 bytes holding states
+// 2h, 2h+1 of each child (so a wave reads 1 KiB contiguous per instruction from the [K x S x 4] tensor), completes the rows
 // with DPP quad_perm moves, produces output states 2h, 2h+1 and stores its 16 bytes (non-temporal: only the
-// few particles that survive the next resampling ever read the node again).  Per 256-site step a pair takes
-// two sites, p + 256 q (-> canonical column p, finished on the even lane) and p + 128 + 256 q (-> column
-// p + 128, odd lane), so every lane runs exactly one log per step.  Arithmetic per output state is the same
+// few particles that survive the next resampling ever read the node again).  Per 64-site step pair p takes
+// two sites, s0 + p + 64 q (-> column p of the tile, finished on the even lane) and s0 + p + 32 + 64 q (-> column
+// p + 32, odd lane), so every lane runs exactly one log per tile.  Arithmetic per output state is the same
 // fma chain as pk_merge_site: results are bit-identical to the row-per-thread form.
 //   algorithmic traffic: 2 x 32 B read + 32 B written per (particle, site) = 96 B / unit.
 // ------------------------------------------------------------------------------------------------
@@ -1247,37 +1284,37 @@ __device__ __forceinline__ void pk_build_leaf_table(const double* __restrict__ P
     }
 }
 
+// sites [s0, s1) of one tile by one wave; lane = 2 p + h
 template <bool CL, bool CR, bool STORE>
-__device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, const double* Lp, const double* Rp,
+__device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, int s0, int s1, const double* Lp, const double* Rp,
                                               const uint8_t* Lc, const uint8_t* Rc, double* out,
                                               const double (&Plc)[4][2], const double (&Prc)[4][2],
                                               const double (*tabL)[4], const double (*tabR)[4], pm_lp& col, int p, int h) {
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
-    const int S = a.S;
     // software pipeline: the next step's rows (or codes) are fetched before this step is computed
     pk_d2 nla = {0, 0}, nra = {0, 0}, nlb = {0, 0}, nrb = {0, 0};
     int ncla = 0, ncra = 0, nclb = 0, ncrb = 0;
-    if (p < S) {
-        if (CL) ncla = Lc[p]; else nla = pk_gload2(Lp + (size_t)p * 4);
-        if (CR) ncra = Rc[p]; else nra = pk_gload2(Rp + (size_t)p * 4);
+    if (s0 + p < s1) {
+        if (CL) ncla = Lc[s0 + p]; else nla = pk_gload2(Lp + (size_t)(s0 + p) * 4);
+        if (CR) ncra = Rc[s0 + p]; else nra = pk_gload2(Rp + (size_t)(s0 + p) * 4);
     }
-    if (p + 128 < S) {
-        if (CL) nclb = Lc[p + 128]; else nlb = pk_gload2(Lp + (size_t)(p + 128) * 4);
-        if (CR) ncrb = Rc[p + 128]; else nrb = pk_gload2(Rp + (size_t)(p + 128) * 4);
+    if (s0 + p + 32 < s1) {
+        if (CL) nclb = Lc[s0 + p + 32]; else nlb = pk_gload2(Lp + (size_t)(s0 + p + 32) * 4);
+        if (CR) ncrb = Rc[s0 + p + 32]; else nrb = pk_gload2(Rp + (size_t)(s0 + p + 32) * 4);
     }
-    const int nq = (S + 255) >> 8;
+    const int nq = (s1 - s0 + 63) >> 6;
     for (int q = 0; q < nq; ++q) {
-        const int sa = p + 256 * q, sb = sa + 128;
-        const bool va = sa < S, vb = sb < S;
+        const int sa = s0 + p + 64 * q, sb = sa + 32;
+        const bool va = sa < s1, vb = sb < s1;
         const pk_d2 la = nla, ra = nra, lb = nlb, rb = nrb;
         const int cla = ncla, cra = ncra, clb = nclb, crb = ncrb;
-        if (sa + 256 < S) {
-            if (CL) ncla = Lc[sa + 256]; else nla = pk_gload2(Lp + (size_t)(sa + 256) * 4);
-            if (CR) ncra = Rc[sa + 256]; else nra = pk_gload2(Rp + (size_t)(sa + 256) * 4);
+        if (sa + 64 < s1) {
+            if (CL) ncla = Lc[sa + 64]; else nla = pk_gload2(Lp + (size_t)(sa + 64) * 4);
+            if (CR) ncra = Rc[sa + 64]; else nra = pk_gload2(Rp + (size_t)(sa + 64) * 4);
         }
-        if (sb + 256 < S) {
-            if (CL) nclb = Lc[sb + 256]; else nlb = pk_gload2(Lp + (size_t)(sb + 256) * 4);
-            if (CR) ncrb = Rc[sb + 256]; else nrb = pk_gload2(Rp + (size_t)(sb + 256) * 4);
+        if (sb + 64 < s1) {
+            if (CL) nclb = Lc[sb + 64]; else nlb = pk_gload2(Lp + (size_t)(sb + 64) * 4);
+            if (CR) ncrb = Rc[sb + 64]; else nrb = pk_gload2(Rp + (size_t)(sb + 64) * 4);
         }
         double lik[2];
 #pragma unroll
@@ -1335,13 +1372,24 @@ __device__ __forceinline__ void pk_merge_epilogue(const pk_rank_args& a, int k, 
     a.logw_r[kg] = lw;
 }
 
-__global__ __launch_bounds__(PK_COLS, 5) void pk_rank_merge(const pk_rank_args a) {
-    __shared__ double cols[PK_COLS];
-    __shared__ double sh4[4];
+// rows longer than one tile: the merge waves left their tiles' values in tilev[k][0 .. ntiles); added left to right
+__global__ __launch_bounds__(256) void pk_tile_epilogue(const pk_rank_args a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.Kloc) return;
+    const double* tv = a.tilev + (size_t)k * a.ntiles;
+    double tot = tv[0];
+    for (int t = 1; t < a.ntiles; ++t) tot = tot + tv[t];
+    pk_merge_epilogue(a, k, a.k0 + k, tot);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void pk_rank_merge(const pk_rank_args a) {
+    __shared__ double cols[64];
     __shared__ __attribute__((aligned(16))) double tabL[5][4], tabR[5][4];
-    const int k = blockIdx.x, kg = a.k0 + k, tid = threadIdx.x, p = tid >> 1, h = tid & 1;
+    const int item = blockIdx.x, k = a.ntiles == 1 ? item : item / a.ntiles, tau = item - k * a.ntiles;
+    const int kg = a.k0 + k, lane = threadIdx.x, p = lane >> 1, h = lane & 1;
+    const int s0 = tau * a.T, s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
     const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
-    const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // workgroup-uniform
+    const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // wave-uniform
     const double* Lp = pk_node_ptr(a, cl) + 2 * h;
     const double* Rp = pk_node_ptr(a, cr) + 2 * h;
     const uint8_t* Lc = a.leaf_codes + (codedL ? (size_t)cl * a.S : 0);
@@ -1357,25 +1405,28 @@ __global__ __launch_bounds__(PK_COLS, 5) void pk_rank_merge(const pk_rank_args a
     }
     if (codedL || codedR) {
         const double* Pu = a.Pmat + (size_t)k * 32;
-        if (tid < 32) pk_build_leaf_table(Pu, tabL, tid);
-        else if (tid < 64) pk_build_leaf_table(Pu + 16, tabR, tid - 32);
+        if (lane < 32) pk_build_leaf_table(Pu, tabL, lane);
+        else pk_build_leaf_table(Pu + 16, tabR, lane - 32);
         __syncthreads();
     }
     pm_lp col = pm_lp_init();
-#define PK_MERGE_DISPATCH(ST)                                                                              \
-    if (codedL) {                                                                                          \
-        if (codedR) pk_merge_body<true, true, ST>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);   \
-        else pk_merge_body<true, false, ST>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);         \
-    } else {                                                                                               \
-        if (codedR) pk_merge_body<false, true, ST>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);  \
-        else pk_merge_body<false, false, ST>(a, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);        \
+#define PK_MERGE_DISPATCH(ST)                                                                                      \
+    if (codedL) {                                                                                                  \
+        if (codedR) pk_merge_body<true, true, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);   \
+        else pk_merge_body<true, false, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);         \
+    } else {                                                                                                       \
+        if (codedR) pk_merge_body<false, true, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);  \
+        else pk_merge_body<false, false, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);        \
     }
     if (a.lazy || a.no_store) { PK_MERGE_DISPATCH(false) } else { PK_MERGE_DISPATCH(true) }
 #undef PK_MERGE_DISPATCH
-    cols[p + 128 * h] = pm_lp_finish(col);          // lane (p, h) owns canonical column p + 128 h
+    cols[p + 32 * h] = pm_lp_finish(col);           // lane (p, h) owns column p + 32 h of the tile
     __syncthreads();
-    const double tot = pk_block_canon_sum(cols[tid], sh4);
-    if (tid == 0) pk_merge_epilogue(a, k, kg, tot);
+    const double tot = pk_wave_tree_sum(cols[lane]);
+    if (lane == 0) {
+        if (a.ntiles == 1) pk_merge_epilogue(a, k, kg, tot);
+        else a.tilev[(size_t)k * a.ntiles + tau] = tot;
+    }
 }
 
 // multi-GPU: after the all-gather of node log-likelihoods, complete the root tables of the other ranks'
@@ -1489,95 +1540,23 @@ __device__ __forceinline__ void pk_build_lik25(const double (*tabL)[4], const do
         lik25[t] = pk_site_lik(pi, o);
     }
 }
-__device__ __forceinline__ void pk_coded_row(const pk_rank_args& a, const uint8_t* Lc, const uint8_t* Rc, const double* lik25, pm_lp& col) {
-    const int tid = threadIdx.x, S = a.S;
-    int cln = 0, crn = 0;
-    if (tid < S) { cln = Lc[tid]; crn = Rc[tid]; }
-    for (int s = tid; s < S; s += PK_COLS) {
-        const int cl = cln, cr = crn;
-        if (s + PK_COLS < S) { cln = Lc[s + PK_COLS]; crn = Rc[s + PK_COLS]; }
-        pm_lp_mul(col, lik25[cl * 5 + cr]);
-    }
-}
-
-template <bool CL, bool CR>
-__device__ __forceinline__ void pk_twist_row(const pk_rank_args& a, const double* Lp, const double* Rp, const uint8_t* Lc,
-                                             const uint8_t* Rc, const double (&Pl)[16], const double (&Pr)[16],
-                                             const double (*tabL)[4], const double (*tabR)[4],
-                                             const double (&pi)[4], pm_lp& col) {
-    const int tid = threadIdx.x, S = a.S;
-    double Ln[4] = {0, 0, 0, 0}, Rn[4] = {0, 0, 0, 0};                 // software pipeline: next step's rows / codes
-    int cln = 0, crn = 0;
-    if (tid < S) {
-        if (CL) cln = Lc[tid]; else pk_load4(Lp + (size_t)tid * 4, Ln);
-        if (CR) crn = Rc[tid]; else pk_load4(Rp + (size_t)tid * 4, Rn);
-    }
-    for (int s = tid; s < S; s += PK_COLS) {
-        double Lv[4], Rv[4], o[4];
-        const int cl = cln, cr = crn;
+// one (pair, sub-sample) row of two coded leaves read through both leaf tables (only when the merge reads codes but the
+// code-pair histogram is absent): sites [s0, s1) of one tile by one wave, lane = column
+__device__ __forceinline__ void pk_twist_row_cc(int s0, int s1, const uint8_t* Lc, const uint8_t* Rc, const double (*tabL)[4],
+                                                const double (*tabR)[4], const double (&pi)[4], pm_lp& col) {
+    const int lane = threadIdx.x & 63;
+    for (int s = s0 + lane; s < s1; s += 64) {
+        const int cl = Lc[s], cr = Rc[s];
+        double o[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { Lv[u] = Ln[u]; Rv[u] = Rn[u]; }
-        if (s + PK_COLS < S) {
-            if (CL) cln = Lc[s + PK_COLS]; else pk_load4(Lp + (size_t)(s + PK_COLS) * 4, Ln);
-            if (CR) crn = Rc[s + PK_COLS]; else pk_load4(Rp + (size_t)(s + PK_COLS) * 4, Rn);
-        }
-        double lpv[4], rpv[4];
-        if (CL) {
-            const pk_d2 x = *reinterpret_cast<const pk_d2*>(&tabL[cl][0]), y = *reinterpret_cast<const pk_d2*>(&tabL[cl][2]);
-            lpv[0] = x.x; lpv[1] = x.y; lpv[2] = y.x; lpv[3] = y.y;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double v = Lv[0] * Pl[j];
-                v = pm_fma(Lv[1], Pl[4 + j], v);
-                v = pm_fma(Lv[2], Pl[8 + j], v);
-                lpv[j] = pm_fma(Lv[3], Pl[12 + j], v);
-            }
-        }
-        if (CR) {
-            const pk_d2 x = *reinterpret_cast<const pk_d2*>(&tabR[cr][0]), y = *reinterpret_cast<const pk_d2*>(&tabR[cr][2]);
-            rpv[0] = x.x; rpv[1] = x.y; rpv[2] = y.x; rpv[3] = y.y;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double v = Rv[0] * Pr[j];
-                v = pm_fma(Rv[1], Pr[4 + j], v);
-                v = pm_fma(Rv[2], Pr[8 + j], v);
-                rpv[j] = pm_fma(Rv[3], Pr[12 + j], v);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = lpv[j] * rpv[j];
+        for (int j = 0; j < 4; ++j) o[j] = tabL[cl][j] * tabR[cr][j];
         pm_lp_mul(col, pk_site_lik(pi, o));
     }
 }
 
-// Contract v4: one (pair, sub-sample) row whose roots are one CODED LEAF and one internal node.  The site likelihood
-// depends on the leaf only through its code c: lik[s] = X[s] . v_c, v_c[i] = sum_j P_int[i][j] (pi_j (leaf_c . P_leaf)[j])
-// (an exact regrouping of pi . ((leaf P_leaf) o (X P_int)); 4 fma per site instead of 24 flops).  vtab = v_c, [5][4].
-__device__ __forceinline__ void pk_twist_row_v4(const pk_rank_args& a, const double* Xp, const uint8_t* cd,
-                                                const double (*vtab)[4], pm_lp& col) {
-    const int tid = threadIdx.x, S = a.S;
-    double Xn[4] = {0, 0, 0, 0};
-    int cn = 0;
-    if (tid < S) { pk_load4(Xp + (size_t)tid * 4, Xn); cn = cd[tid]; }
-    for (int s = tid; s < S; s += PK_COLS) {
-        const double x0 = Xn[0], x1 = Xn[1], x2 = Xn[2], x3 = Xn[3];
-        const int c = cn;
-        if (s + PK_COLS < S) { pk_load4(Xp + (size_t)(s + PK_COLS) * 4, Xn); cn = cd[s + PK_COLS]; }
-        const pk_d2 va = *reinterpret_cast<const pk_d2*>(&vtab[c][0]), vb = *reinterpret_cast<const pk_d2*>(&vtab[c][2]);
-        double lik = x0 * va.x;
-        lik = pm_fma(x1, va.y, lik);
-        lik = pm_fma(x2, vb.x, lik);
-        lik = pm_fma(x3, vb.y, lik);
-        pm_lp_mul(col, lik);
-    }
-}
-
-// One workgroup per (local particle, left root r1): all pairs (r1, r2 > r1) x M sub-samples.  Thread c owns
-// canonical column c (sites c, c+256, ...) of every pair; column sums go to LDS and each wave then runs the
-// canonical tree for whole (pair, sub-sample) rows, so there is one barrier per workgroup instead of two per
-// potential.  Nothing is stored but the potentials.  fp64-VALU bound (about 80 flops per particle-site-pair).
+// pk_twist_potentials (below): one workgroup per (local particle, left root r1): all pairs (r1, r2 > r1) x M sub-samples,
+// one WAVE per (pair, sub-sample) row at a time (lane = column of the site tile).  Nothing is stored but the potentials.
+// fp64-VALU bound (about 80 flops per particle-site-pair).
 // force a wave-uniform value into scalar registers (the compiler keeps uniform loads in VGPRs once the
 // kernel has stored to global memory)
 __device__ __forceinline__ double pk_uniform(double v) {
@@ -1599,8 +1578,8 @@ typedef __attribute__((address_space(1))) const pk_u4 pk_gu4c;
 typedef __attribute__((address_space(1))) const uint8_t pk_gu8c;
 struct pk_rowregs { pk_u4 l0, l1, r0, r1; unsigned int cl, cr; };
 // wave-uniform base (scalar registers) + one 32-bit byte offset per thread: hipcc then emits the `saddr` form of global_load, with
-// no 64-bit address arithmetic on the vector pipe.  The site index is clamped (a site past the end re-reads the last one and is
-// not used), so no branch surrounds a load.
+// no 64-bit address arithmetic on the vector pipe.  The site index is clamped (a site past the end re-reads the last one and its
+// factor is replaced by exactly 1.0), so no branch surrounds a load.
 __device__ __forceinline__ const char* pk_uniform_ptr(const void* p) {
     const unsigned long long v = (unsigned long long)p;
     const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
@@ -1608,19 +1587,20 @@ __device__ __forceinline__ const char* pk_uniform_ptr(const void* p) {
     return (const char*)(((unsigned long long)hi << 32) | lo);
 }
 template <bool CL, bool CR>
-__device__ __forceinline__ void pk_rows_load(pk_rowregs& x, const char* bl, const char* br, int s, int S) {
-    const unsigned int sc = (unsigned int)(s < S ? s : S - 1);
+__device__ __forceinline__ void pk_rows_load(pk_rowregs& x, const char* bl, const char* br, int s, int s1) {
+    const unsigned int sc = (unsigned int)(s < s1 ? s : s1 - 1);
     if constexpr (CL) x.cl = *(pk_gu8c*)(bl + sc);
     else { x.l0 = *(pk_gu4c*)(bl + sc * 32u); x.l1 = *(pk_gu4c*)(bl + sc * 32u + 16u); }
     if constexpr (CR) x.cr = *(pk_gu8c*)(br + sc);
     else { x.r0 = *(pk_gu4c*)(br + sc * 32u); x.r1 = *(pk_gu4c*)(br + sc * 32u + 16u); }
 }
 __device__ __forceinline__ double pk_u2d(unsigned int lo, unsigned int hi) { return __hiloint2double((int)hi, (int)lo); }
+// the site likelihood pi . ((L P_l) o (R P_r)) of the loaded rows / codes
 template <bool CL, bool CR>
-__device__ __forceinline__ void pk_rows_site(const pk_rowregs& x, const double (&Pl)[16], const double (&Pr)[16], const double (*tabL)[4],
-                                             const double (*tabR)[4], const double* lik25, const double (&pi)[4], pm_lp& col) {
+__device__ __forceinline__ double pk_rows_lik(const pk_rowregs& x, const double (&Pl)[16], const double (&Pr)[16], const double (*tabL)[4],
+                                              const double (*tabR)[4], const double* lik25, const double (&pi)[4]) {
     if constexpr (CL && CR) {
-        pm_lp_mul(col, lik25[x.cl * 5 + x.cr]);
+        return lik25[x.cl * 5 + x.cr];
     } else {
         double lpv[4], rpv[4], o[4];
         if constexpr (CL) {
@@ -1651,51 +1631,62 @@ __device__ __forceinline__ void pk_rows_site(const pk_rowregs& x, const double (
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = lpv[j] * rpv[j];
-        pm_lp_mul(col, pk_site_lik(pi, o));
+        return pk_site_lik(pi, o);
     }
 }
-// the loop alone: sites tid, tid + 256, ... of one (left, right) pair with the first register set already loaded
+// the loop alone: sites s0 + lane + 64 j < s1 of one tile by one wave (lane = column of the tile), the first register set
+// already loaded.  Two sites per trip, ONE renormalisation of the running product for both (pm_lp_mul2: the bits of two
+// pm_lp_mul); the trip count is wave-uniform, a lane past the end multiplies by exactly 1.0.
 template <bool CL, bool CR>
-__device__ __forceinline__ void pk_rows_run(int S, const char* bl, const char* br, pk_rowregs& A, const double (&Pl)[16], const double (&Pr)[16],
-                                            const double (*tabL)[4], const double (*tabR)[4], const double* lik25, const double (&pi)[4],
-                                            pm_lp& col) {
+__device__ __forceinline__ void pk_rows_run(int s0, int s1, const char* bl, const char* br, pk_rowregs& A, const double (&Pl)[16],
+                                            const double (&Pr)[16], const double (*tabL)[4], const double (*tabR)[4], const double* lik25,
+                                            const double (&pi)[4], pm_lp& col) {
     pk_rowregs B;
-    int s = threadIdx.x;
+    int s = s0 + (int)(threadIdx.x & 63);
     #pragma unroll 1
-    for (; s < S; s += 2 * PK_COLS) {
-        pk_rows_load<CL, CR>(B, bl, br, s + PK_COLS, S);
-        pk_rows_site<CL, CR>(A, Pl, Pr, tabL, tabR, lik25, pi, col);
-        pk_rows_load<CL, CR>(A, bl, br, s + 2 * PK_COLS, S);
-        if (s + PK_COLS < S) pk_rows_site<CL, CR>(B, Pl, Pr, tabL, tabR, lik25, pi, col);
+    for (int u = s0; u < s1; u += 128, s += 128) {          // u: wave-uniform
+        pk_rows_load<CL, CR>(B, bl, br, s + 64, s1);
+        double xa = pk_rows_lik<CL, CR>(A, Pl, Pr, tabL, tabR, lik25, pi);
+        xa = s < s1 ? xa : 1.0;
+        pk_rows_load<CL, CR>(A, bl, br, s + 128, s1);
+        if (u + 64 < s1) {
+            double xb = pk_rows_lik<CL, CR>(B, Pl, Pr, tabL, tabR, lik25, pi);
+            xb = s + 64 < s1 ? xb : 1.0;
+            pm_lp_mul2(col, xa, xb);
+        } else {
+            pm_lp_mul(col, xa);
+        }
     }
 }
+// one tile of one merge by one wave (a 64-thread workgroup: the barriers below are wave barriers)
 template <bool CL, bool CR>
-__device__ __forceinline__ void pk_rows_loop(int S, const double* Lp, const double* Rp, const uint8_t* Lc, const uint8_t* Rc,
+__device__ __forceinline__ void pk_rows_loop(int s0, int s1, const double* Lp, const double* Rp, const uint8_t* Lc, const uint8_t* Rc,
                                              const double* Pu, const double* pi4, const double (&Pl)[16], const double (&Pr)[16],
                                              double (*tabL)[4], double (*tabR)[4], double* lik25, const double (&pi)[4], pm_lp& col) {
+    const int lane = threadIdx.x & 63;
     const char* bl = pk_uniform_ptr(CL ? (const void*)Lc : (const void*)Lp);
     const char* br = pk_uniform_ptr(CR ? (const void*)Rc : (const void*)Rp);
     pk_rowregs A;
-    pk_rows_load<CL, CR>(A, bl, br, threadIdx.x, S);       // the first rows / codes travel while the leaf tables are built
-    if constexpr (CL || CR) {                              // (the whole workgroup takes the same variant: the barriers are uniform)
-        if (threadIdx.x < 32) pk_build_leaf_table(Pu, tabL, threadIdx.x);
-        else if (threadIdx.x < 64) pk_build_leaf_table(Pu + 16, tabR, threadIdx.x - 32);
+    pk_rows_load<CL, CR>(A, bl, br, s0 + lane, s1);        // the first rows / codes travel while the leaf tables are built
+    if constexpr (CL || CR) {                              // (the whole wave takes the same variant)
+        if (lane < 32) pk_build_leaf_table(Pu, tabL, lane);
+        else pk_build_leaf_table(Pu + 16, tabR, lane - 32);
         __syncthreads();
     }
     if constexpr (CL && CR) {
-        pk_build_lik25(tabL, tabR, pi4, lik25, threadIdx.x);
+        pk_build_lik25(tabL, tabR, pi4, lik25, lane);
         __syncthreads();
     }
-    pk_rows_run<CL, CR>(S, bl, br, A, Pl, Pr, tabL, tabR, lik25, pi, col);
+    pk_rows_run<CL, CR>(s0, s1, bl, br, A, Pl, Pr, tabL, tabR, lik25, pi, col);
 }
 // contract v4 row (one coded leaf, one internal root X): lik[s] = X[s] . v_code[s], same two-register-set loop
-__device__ __forceinline__ void pk_rows_v4(int S, const double* Xp, const uint8_t* cd, const double (*vtab)[4], pm_lp& col) {
+__device__ __forceinline__ void pk_rows_v4(int s0, int s1, const double* Xp, const uint8_t* cd, const double (*vtab)[4], pm_lp& col) {
     const char* bx = pk_uniform_ptr(Xp);
     const char* bc = pk_uniform_ptr(cd);
     pk_u4 a0, a1, b0, b1;
     unsigned int ca, cb;
     auto load = [&](pk_u4& x0, pk_u4& x1, unsigned int& c, int s) {
-        const unsigned int sc = (unsigned int)(s < S ? s : S - 1);
+        const unsigned int sc = (unsigned int)(s < s1 ? s : s1 - 1);
         x0 = *(pk_gu4c*)(bx + sc * 32u); x1 = *(pk_gu4c*)(bx + sc * 32u + 16u);
         c = *(pk_gu8c*)(bc + sc);
     };
@@ -1705,27 +1696,35 @@ __device__ __forceinline__ void pk_rows_v4(int S, const double* Xp, const uint8_
         lik = pm_fma(pk_u2d(x0.z, x0.w), va.y, lik);
         lik = pm_fma(pk_u2d(x1.x, x1.y), vb.x, lik);
         lik = pm_fma(pk_u2d(x1.z, x1.w), vb.y, lik);
-        pm_lp_mul(col, lik);
+        return lik;
     };
-    int s = threadIdx.x;
+    int s = s0 + (int)(threadIdx.x & 63);
     load(a0, a1, ca, s);
     #pragma unroll 1
-    for (; s < S; s += 2 * PK_COLS) {
-        load(b0, b1, cb, s + PK_COLS);
-        site(a0, a1, ca);
-        load(a0, a1, ca, s + 2 * PK_COLS);
-        if (s + PK_COLS < S) site(b0, b1, cb);
+    for (int u = s0; u < s1; u += 128, s += 128) {
+        load(b0, b1, cb, s + 64);
+        double xa = site(a0, a1, ca);
+        xa = s < s1 ? xa : 1.0;
+        load(a0, a1, ca, s + 128);
+        if (u + 64 < s1) {
+            double xb = site(b0, b1, cb);
+            xb = s + 64 < s1 ? xb : 1.0;
+            pm_lp_mul2(col, xa, xb);
+        } else {
+            pm_lp_mul(col, xa);
+        }
     }
 }
 
-__global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_rank_args a) {
-    __shared__ double cols[PK_COLS];
-    __shared__ double sh4[4];
+// The merge of one rank event when the new node is NOT stored (lazy nodes, the last rank event): one WAVE per (particle, tile),
+// grid = Kloc x ntiles workgroups of 64.  The wave's matrices, pointers and site bounds are wave-uniform (scalar registers).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void pk_rank_merge_nostore(const pk_rank_args a) {
     __shared__ __attribute__((aligned(16))) double tabL[5][4], tabR[5][4];
     __shared__ double lik25[25];
-    const int k = blockIdx.x, kg = a.k0 + k, tid = threadIdx.x;
+    const int item = blockIdx.x, ntiles = a.ntiles, k = ntiles == 1 ? item : item / ntiles, tau = item - k * ntiles;
+    const int s0 = tau * a.T, s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
     const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
-    const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // workgroup-uniform
+    const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // wave-uniform
     const double* Lp = pk_node_ptr(a, cl);
     const double* Rp = pk_node_ptr(a, cr);
     const uint8_t* Lc = a.leaf_codes + (codedL ? (size_t)cl * a.S : 0);
@@ -1737,29 +1736,32 @@ __global__ __launch_bounds__(PK_COLS, 4) void pk_rank_merge_nostore(const pk_ran
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     pm_lp col = pm_lp_init();
     if (codedL) {
-        if (codedR) pk_rows_loop<true, true>(a.S, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
-        else pk_rows_loop<true, false>(a.S, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
+        if (codedR) pk_rows_loop<true, true>(s0, s1, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
+        else pk_rows_loop<true, false>(s0, s1, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
     } else {
-        if (codedR) pk_rows_loop<false, true>(a.S, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
-        else pk_rows_loop<false, false>(a.S, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
+        if (codedR) pk_rows_loop<false, true>(s0, s1, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
+        else pk_rows_loop<false, false>(s0, s1, Lp, Rp, Lc, Rc, Pu, a.pi, Pl, Pr, tabL, tabR, lik25, pi, col);
     }
-    cols[tid] = pm_lp_finish(col);
-    __syncthreads();
-    const double tot = pk_block_canon_sum(cols[tid], sh4);
-    if (tid == 0) {
+    const double tot = pk_wave_tree_sum(pm_lp_finish(col));
+    if (threadIdx.x == 0) {
         // the epilogue's pointers are read from the kernel-argument segment HERE: taken from `a` they are loaded at the top of the
         // kernel and stay live in scalar registers through the row loops, next to the 64 registers of P_l and P_r
         typedef __attribute__((address_space(4))) const pk_rank_args pk_kernarg;
         pk_kernarg* ka = (pk_kernarg*)__builtin_amdgcn_kernarg_segment_ptr();
-        const double* ax = ka->aux + (size_t)k * PK_AUX;
-        const double fl = ax[AUX_SUM_REM] + tot;
-        const double ll = ((fl + ax[AUX_FPRIOR]) + ax[AUX_LPRIOR]) + ax[AUX_RPRIOR];
-        const double lw = (((ll - ax[AUX_LL_TILDE]) - ax[AUX_PAREN]) + ax[AUX_LOGV]) - ax[AUX_Q];
-        const int N = ka->N, r = ka->r, K = ka->K;
-        ka->nodell[N + r * K + kg] = tot;
-        ka->rootll_new[(size_t)kg * N + (ka->n - 2)] = tot;
-        ka->ll_r[kg] = ll;
-        ka->logw_r[kg] = lw;
+        if (ka->ntiles != 1) {
+            ka->tilev[(size_t)k * ka->ntiles + tau] = tot;
+        } else {
+            const int kg = ka->k0 + k;
+            const double* ax = ka->aux + (size_t)k * PK_AUX;
+            const double fl = ax[AUX_SUM_REM] + tot;
+            const double ll = ((fl + ax[AUX_FPRIOR]) + ax[AUX_LPRIOR]) + ax[AUX_RPRIOR];
+            const double lw = (((ll - ax[AUX_LL_TILDE]) - ax[AUX_PAREN]) + ax[AUX_LOGV]) - ax[AUX_Q];
+            const int N = ka->N, r = ka->r, K = ka->K;
+            ka->nodell[N + r * K + kg] = tot;
+            ka->rootll_new[(size_t)kg * N + (ka->n - 2)] = tot;
+            ka->ll_r[kg] = ll;
+            ka->logw_r[kg] = lw;
+        }
     }
 }
 
@@ -1774,7 +1776,7 @@ __device__ __forceinline__ double pk_leaf_entry(const double* __restrict__ P, in
 
 // Potentials of the pairs of two CODED LEAVES: the merged row takes 25 distinct values, so
 // sum_s log f(c_l[s], c_r[s]) = sum over code pairs c of count_c log f_c (contract v3): the
-// term of code pair c sits in canonical column c, every other column is 0, same tree.  32 lanes per
+// term of code pair c sits in column c of ONE 64-column tile, every other column is 0, same tree.  32 lanes per
 // (particle, pair, sub-sample) row; rows of other pairs leave at once (pk_twist_potentials computes those).
 __global__ __launch_bounds__(256) void pk_twist_potentials_ll(const pk_twist_args ta) {
     __shared__ __attribute__((aligned(16))) double Psh[8][32];
@@ -1818,8 +1820,7 @@ __global__ __launch_bounds__(256) void pk_twist_potentials_ll(const pk_twist_arg
 #pragma unroll
     for (int off = 1; off < 32; off <<= 1) v = v + __shfl_xor(v, off, 64);
     if (c == 0) {
-        v = v + 0.0;                                           // column 32 of the 64-column tree
-        const double tot = ((v + 0.0) + 0.0) + 0.0;            // column groups 1..3
+        const double tot = v + 0.0;                            // columns 32..63 of the (single) tile's tree are 0
         const int32_t* co = ta.cnt_ad + (size_t)kg * a.N;
         const double* rl = ta.rootll_ad + (size_t)kg * a.N;
         const int c1 = co[r1], c2 = co[r2], c12 = c1 + c2;
@@ -1830,8 +1831,7 @@ __global__ __launch_bounds__(256) void pk_twist_potentials_ll(const pk_twist_arg
     }
 }
 
-__global__ __launch_bounds__(PK_COLS, 6) void pk_twist_potentials(const pk_twist_args ta) {
-    __shared__ double cols[PK_TWIST_LDS_ROWS][PK_COLS];
+__global__ __launch_bounds__(PK_COLS, 5) void pk_twist_potentials(const pk_twist_args ta) {
     __shared__ __attribute__((aligned(16))) double Psh[PK_TWIST_LDS_ROWS][32];
     __shared__ __attribute__((aligned(16))) double tab[PK_TWIST_LDS_ROWS][2][5][4];
     __shared__ __attribute__((aligned(16))) double vsh[PK_TWIST_LDS_ROWS][5][4];   // contract v4 tables of the staged rows
@@ -1900,56 +1900,55 @@ __global__ __launch_bounds__(PK_COLS, 6) void pk_twist_potentials(const pk_twist
             }
             __syncthreads();
         }
-        for (int q = 0; q < cnt; ++q) {
+        // contract v5: one WAVE per (pair, sub-sample) row, lane = column of the tile, tiles left to right; no barrier, no LDS
+        // between a row's sites and its potential
+        for (int q = wv; q < cnt; q += 4) {
             const int row = rowlist[base + q], r2 = r1 + 1 + row / M;
             const int idr = ro[r2];
             const double* Rp = pk_node_ptr(a, idr);
-            if (ta.codes && ((idl < a.N) != (idr < a.N))) {       // coded leaf x internal root: contract v4
-                pm_lp colv = pm_lp_init();
-                if (idl < a.N) pk_rows_v4(a.S, Rp, ta.codes + (size_t)idl * a.S, vsh[q], colv);
-                else pk_rows_v4(a.S, Lp, ta.codes + (size_t)idr * a.S, vsh[q], colv);
-                cols[q][tid] = pm_lp_finish(colv);
-                continue;
-            }
-            const bool cR = a.leaf_codes && idr < a.N;
-            double Pl[16], Pr[16];
+            double tot = 0.0;
+            if (ta.codes && ((idl < a.N) != (idr < a.N))) {                    // coded leaf x internal root: contract v4
+                const double* Xp = idl < a.N ? Rp : Lp;
+                const uint8_t* cd = ta.codes + (size_t)(idl < a.N ? idl : idr) * a.S;
+                for (int s0 = 0; s0 < a.S; s0 += a.T) {
+                    const int s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
+                    pm_lp col = pm_lp_init();
+                    pk_rows_v4(s0, s1, Xp, cd, vsh[q], col);
+                    const double t = pk_wave_tree_sum(pm_lp_finish(col));
+                    tot = s0 ? tot + t : t;
+                }
+            } else {
+                const bool cR = a.leaf_codes && idr < a.N;
+                const uint8_t* Lc = a.leaf_codes + (cL ? (size_t)idl * a.S : 0);
+                const uint8_t* Rc = a.leaf_codes + (cR ? (size_t)idr * a.S : 0);
+                double Pl[16], Pr[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { Pl[u] = pk_uniform(Psh[q][u]); Pr[u] = pk_uniform(Psh[q][16 + u]); }   // P_l in SGPRs
-            pm_lp col = pm_lp_init();
-            const uint8_t* Lc = a.leaf_codes + (cL ? (size_t)idl * a.S : 0);
-            const uint8_t* Rc = a.leaf_codes + (cR ? (size_t)idr * a.S : 0);
-            if (cL && cR) pk_twist_row<true, true>(a, Lp, Rp, Lc, Rc, Pl, Pr, tab[q][0], tab[q][1], pi, col);
-            else {
-                pk_rowregs A;
-                if (cL) {
-                    const char* bl = pk_uniform_ptr(Lc); const char* br = pk_uniform_ptr(Rp);
-                    pk_rows_load<true, false>(A, bl, br, tid, a.S);
-                    pk_rows_run<true, false>(a.S, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
-                } else if (cR) {
-                    const char* bl = pk_uniform_ptr(Lp); const char* br = pk_uniform_ptr(Rc);
-                    pk_rows_load<false, true>(A, bl, br, tid, a.S);
-                    pk_rows_run<false, true>(a.S, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
-                } else {
-                    const char* bl = pk_uniform_ptr(Lp); const char* br = pk_uniform_ptr(Rp);
-                    pk_rows_load<false, false>(A, bl, br, tid, a.S);
-                    pk_rows_run<false, false>(a.S, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
+                for (int u = 0; u < 16; ++u) { Pl[u] = pk_uniform(Psh[q][u]); Pr[u] = pk_uniform(Psh[q][16 + u]); }   // scalar registers
+                for (int s0 = 0; s0 < a.S; s0 += a.T) {
+                    const int s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
+                    pm_lp col = pm_lp_init();
+                    pk_rowregs A;
+                    if (cL && cR) {
+                        pk_twist_row_cc(s0, s1, Lc, Rc, tab[q][0], tab[q][1], pi, col);
+                    } else if (cL) {
+                        const char* bl = pk_uniform_ptr(Lc); const char* br = pk_uniform_ptr(Rp);
+                        pk_rows_load<true, false>(A, bl, br, s0 + lane, s1);
+                        pk_rows_run<true, false>(s0, s1, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
+                    } else if (cR) {
+                        const char* bl = pk_uniform_ptr(Lp); const char* br = pk_uniform_ptr(Rc);
+                        pk_rows_load<false, true>(A, bl, br, s0 + lane, s1);
+                        pk_rows_run<false, true>(s0, s1, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
+                    } else {
+                        const char* bl = pk_uniform_ptr(Lp); const char* br = pk_uniform_ptr(Rp);
+                        pk_rows_load<false, false>(A, bl, br, s0 + lane, s1);
+                        pk_rows_run<false, false>(s0, s1, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
+                    }
+                    const double t = pk_wave_tree_sum(pm_lp_finish(col));
+                    tot = s0 ? tot + t : t;
                 }
             }
-            cols[q][tid] = pm_lp_finish(col);
-        }
-        __syncthreads();
-        for (int q = wv; q < cnt; q += 4) {               // canonical tree of one row per wave
-            double g[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                double v = cols[q][lane + 64 * u];
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
-                g[u] = v;
-            }
             if (lane == 0) {
-                const double tot = ((g[0] + g[1]) + g[2]) + g[3];
-                const int row = rowlist[base + q], r2 = r1 + 1 + row / M, m = row - (row / M) * M;
+                const int m = row - (row / M) * M;
                 const int c1 = co[r1], c2 = co[r2], c12 = c1 + c2;
                 double jp = tot + (-a.ldf[c12 < a.ldf_n ? c12 : a.ldf_n]);
                 jp = jp - (rl[r1] + (-a.ldf[c1 < a.ldf_n ? c1 : a.ldf_n]));

@@ -172,7 +172,14 @@ PM_HD double pm_log(double x) {
 // one per site, and a smaller rounding error than adding up logs).  Factors that are not positive normal
 // numbers (zero, subnormal, negative, inf, NaN) go through pm_log into `extra` so their special values
 // propagate exactly as they would in a plain sum of logs.
+//
+// Contract v5: the S sites of a row are cut into TILES of T = site tile sites (a multiple of 64;
+// pm_site_tile is the policy, a context can override it); inside a tile, site s belongs to column (s - tile start) mod 64
+// -- ONE WAVE owns a (row, tile), lane = column -- ; the 64 finished columns are added by the adjacent-pair tree and the tile
+// values left to right.
 // ------------------------------------------------------------------------------------------------
+PM_HD int pm_site_tile(int S) { (void)S; return 2048; }
+
 struct pm_lp { double p; int E; double extra; };
 
 PM_HD pm_lp pm_lp_init() { pm_lp a = {1.0, 0, 0.0}; return a; }
@@ -190,6 +197,26 @@ PM_HD void pm_lp_mul(pm_lp& a, double x) {
     const uint64_t bp = pm_bits(a.p);
     a.E += (ex - 1023) + ((int)((bp >> 52) & 0x7ff) - 1023);
     a.p = pm_from_bits((bp & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+}
+
+// Two factors with ONE renormalisation -- bit for bit pm_lp_mul(a, x1); pm_lp_mul(a, x2), for every input:
+//   x = m 2^e with m in [1,2): fl(p x) = fl(p m) 2^e as long as nothing leaves the normal range (rounding to 53 bits does not
+//   depend on the scale), so q = fl(fl(p x1) x2) carries the mantissa of the two per-factor updates and the sum of their
+//   exponents.  p >= 1 and x1 >= 2^-1022 keep fl(p x1) out of the subnormals; an overflow there gives q = inf; the second
+//   product was rounded with full precision iff q >= 2^-1021 (a q that ROUNDS UP to 2^-1022 was rounded on the subnormal grid).
+//   So: both factors positive normal and 2^-1021 <= q < inf -> take q; anything else -> the two per-factor updates.
+PM_HD void pm_lp_mul2(pm_lp& a, double x1, double x2) {
+    const double q = (a.p * x1) * x2;
+    const uint64_t bq = pm_bits(q);
+    const uint32_t h1 = (uint32_t)(pm_bits(x1) >> 32), h2 = (uint32_t)(pm_bits(x2) >> 32), hq = (uint32_t)(bq >> 32);
+    const bool ok = (h1 - 0x00100000u < 0x7fe00000u) & (h2 - 0x00100000u < 0x7fe00000u) & (hq - 0x00200000u < 0x7fd00000u);
+    if (ok) {
+        a.E += (int)(hq >> 20) - 1023;
+        a.p = pm_from_bits((bq & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    } else {
+        pm_lp_mul(a, x1);
+        pm_lp_mul(a, x2);
+    }
 }
 
 PM_HD double pm_lp_finish(const pm_lp& a) {

@@ -19,8 +19,8 @@
 // previous rank event were adopted (lazy nodes: only those are ever read again) and writes exactly those into the pool
 // before its own merges; a merge that needs a node written during the same rank event waits on that node's mark.
 // Owners never wait while they write, so the waits cannot form a cycle; every spin is bounded and reports a timeout.
-// Merges: one WAVE per particle (no workgroup barrier inside a merge): lane l owns canonical columns l, l + 64, l + 128,
-// l + 192 (sites l + 64 j), the column tree is four in-wave butterflies.  Arithmetic, orders and outputs are those of the
+// Merges: one WAVE per particle (no workgroup barrier inside a merge): lane l owns column l of every site tile (contract v5:
+// sites tile start + l + 64 j), the column tree is one in-wave butterfly per tile.  Arithmetic, orders and outputs are those of the
 // launch path (phylo_kernels.h) bit for bit; tests compare both with the C oracle.
 #pragma once
 #include "phylo_kernels.h"
@@ -33,6 +33,7 @@
 
 struct pp_args {
     int N, S, K, Kg, G, R;           // K = G * Kg particles, R = N - 1 rank events
+    int T;                           // contract v5: sites per tile of the canonical sum over sites
     int Wg, m;                       // workgroups per group, particles per workgroup (Kg = Wg * m); grid = G * Wg
     uint64_t seed;                   // G == 1
     const uint64_t* group_seeds;     // [G] or NULL
@@ -151,20 +152,8 @@ __device__ __forceinline__ double pp_lp_finish(const pm_lp& a) {
 // then read by lane and added as (r0 + r1) + (r2 + r3).  a + b is commutative bit for bit: same result as the butterfly,
 // without its six dependent trips through the LDS crossbar.
 template <int CTRL>
-__device__ __forceinline__ double pp_dpp(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double pp_wave_tree_sum(double v) {
-    v = v + pp_dpp<0xB1>(v);          // quad_perm [1,0,3,2]: xor 1
-    v = v + pp_dpp<0x4E>(v);          // quad_perm [2,3,0,1]: xor 2
-    v = v + pp_dpp<0x141>(v);         // row_half_mirror: the other quad of my 8
-    v = v + pp_dpp<0x140>(v);         // row_mirror: the other 8 of my row
-    const double r0 = pp_readlane(v, 0), r1 = pp_readlane(v, 16), r2 = pp_readlane(v, 32), r3 = pp_readlane(v, 48);
-    return (r0 + r1) + (r2 + r3);
-}
+__device__ __forceinline__ double pp_dpp(double v) { return pk_dpp<CTRL>(v); }
+__device__ __forceinline__ double pp_wave_tree_sum(double v) { return pk_wave_tree_sum(v); }
 
 // wave maximum by the same DPP steps (max is exact and commutative), wave-uniform result
 __device__ __forceinline__ double pp_wave_max(double v) {
@@ -423,40 +412,40 @@ __device__ __forceinline__ void pp_part_a(const pp_args& a, int r, int kg, uint3
     pp_stamp(a, r, 14);
 }
 
-// ---- the merge of one particle by ONE wave: lane l owns canonical columns l + 64 u (u = 0..3), i.e. sites l + 64 j.
-//      With one wave per SIMD nothing else hides a memory round trip, so the rows / codes of the NEXT four site steps are
-//      in flight while four are computed (two register sets, ping-pong; the loop stays rolled: instruction cache).
+// ---- the merge of one particle by ONE wave, tile after tile: lane l owns column l of the tile, i.e. sites s0 + l + 64 j.
+//      With one wave per SIMD nothing else hides a memory round trip, so the rows / codes of the NEXT BS site steps are
+//      in flight while BS are computed (two register sets, ping-pong; the loop stays rolled: instruction cache).
 template <bool CL, bool CR, int BS>
 struct pp_blk {
     pk_d2 La[CL ? 1 : BS][2], Ra[CR ? 1 : BS][2];
     int cl[CL ? BS : 1], cr[CR ? BS : 1];
 };
 template <bool CL, bool CR, int BS>
-__device__ __forceinline__ void pp_blk_load(pp_blk<CL, CR, BS>& b, int S, int it0, const double* Lp, const double* Rp, const uint8_t* Lc,
+__device__ __forceinline__ void pp_blk_load(pp_blk<CL, CR, BS>& b, int s0, int s1, int it0, const double* Lp, const double* Rp, const uint8_t* Lc,
                                             const uint8_t* Rc, int lane) {
     // no branch around a load (hipcc then counts its waits exactly and keeps the next block in flight): a site step past
     // the end re-reads the last site; its factor is replaced by 1.0 below
 #pragma unroll
     for (int u = 0; u < BS; ++u) {
-        int s = lane + 64 * (it0 + u);
-        s = s < S ? s : S - 1;
+        int s = s0 + lane + 64 * (it0 + u);
+        s = s < s1 ? s : s1 - 1;
         if constexpr (CL) b.cl[u] = Lc[s]; else { b.La[u][0] = pk_gload2(Lp + (size_t)s * 4); b.La[u][1] = pk_gload2(Lp + (size_t)s * 4 + 2); }
         if constexpr (CR) b.cr[u] = Rc[s]; else { b.Ra[u][0] = pk_gload2(Rp + (size_t)s * 4); b.Ra[u][1] = pk_gload2(Rp + (size_t)s * 4 + 2); }
     }
 }
-template <bool CL, bool CR, int BS, int C0>
-__device__ __forceinline__ void pp_blk_compute(const pp_blk<CL, CR, BS>& b, int S, int it0, const double (&Pl)[16], const double (&Pr)[16],
+template <bool CL, bool CR, int BS>
+__device__ __forceinline__ void pp_blk_compute(const pp_blk<CL, CR, BS>& b, int s0, int s1, int it0, const double (&Pl)[16], const double (&Pr)[16],
                                                const double (*tabL)[4], const double (*tabR)[4], const double* lik25,
-                                               const double (&pi)[4], pm_lp (&col)[4], bool& special, int lane) {
+                                               const double (&pi)[4], pm_lp& col, bool& special, int lane) {
 #pragma unroll
     for (int u = 0; u < BS; ++u) {
-        const int s = lane + 64 * (it0 + u);
+        const int s = s0 + lane + 64 * (it0 + u);
         if constexpr (CL && CR) {                       // two coded leaves: one of 25 memoised site likelihoods
             double lik = lik25[b.cl[u] * 5 + b.cr[u]];
-            lik = s < S ? lik : 1.0;
+            lik = s < s1 ? lik : 1.0;
             const bool sp = pp_lp_special(lik);
             special |= sp;
-            pp_lp_mul_fast(col[(C0 + u) & 3], sp ? 1.0 : lik);
+            pp_lp_mul_fast(col, sp ? 1.0 : lik);
         } else {
             double lpv[4], rpv[4], o[4];
             if constexpr (CL) {
@@ -490,62 +479,59 @@ __device__ __forceinline__ void pp_blk_compute(const pp_blk<CL, CR, BS>& b, int 
             // a factor of exactly 1.0 leaves the running product's mantissa and exponent bit for bit unchanged.  A factor that is
             // not a positive normal number (pm_lp_mul's rare branch) is only flagged here: the caller redoes the particle out of line
             double lik = pk_site_lik(pi, o);
-            lik = s < S ? lik : 1.0;
+            lik = s < s1 ? lik : 1.0;
             const bool sp = pp_lp_special(lik);
             special |= sp;
-            pp_lp_mul_fast(col[(C0 + u) & 3], sp ? 1.0 : lik);
+            pp_lp_mul_fast(col, sp ? 1.0 : lik);
         }
     }
 }
+// sites [s0, s1) of one tile
 template <bool CL, bool CR, int BS>
-__device__ __forceinline__ bool pp_merge_wave(int S, const double* Lp, const double* Rp, const uint8_t* Lc, const uint8_t* Rc,
+__device__ __forceinline__ bool pp_merge_wave(int s0, int s1, const double* Lp, const double* Rp, const uint8_t* Lc, const uint8_t* Rc,
                                               const double (&Pl)[16], const double (&Pr)[16], const double (*tabL)[4],
-                                              const double (*tabR)[4], const double* lik25, const double (&pi)[4], pm_lp (&col)[4],
+                                              const double (*tabR)[4], const double* lik25, const double (&pi)[4], pm_lp& col,
                                               int lane) {
-    const int nit = (S + 63) >> 6;
+    const int nit = (s1 - s0 + 63) >> 6;
     bool special = false;
-    pp_blk<CL, CR, BS> A, B;                               // BS = 4: each block covers columns 0..3; BS = 2: A columns 0,1, B columns 2,3
-    pp_blk_load<CL, CR, BS>(A, S, 0, Lp, Rp, Lc, Rc, lane);
+    pp_blk<CL, CR, BS> A, B;
+    pp_blk_load<CL, CR, BS>(A, s0, s1, 0, Lp, Rp, Lc, Rc, lane);
     #pragma unroll 1
     for (int it0 = 0; it0 < nit; it0 += 2 * BS) {
-        pp_blk_load<CL, CR, BS>(B, S, it0 + BS, Lp, Rp, Lc, Rc, lane);
-        pp_blk_compute<CL, CR, BS, 0>(A, S, it0, Pl, Pr, tabL, tabR, lik25, pi, col, special, lane);
-        pp_blk_load<CL, CR, BS>(A, S, it0 + 2 * BS, Lp, Rp, Lc, Rc, lane);
-        pp_blk_compute<CL, CR, BS, BS>(B, S, it0 + BS, Pl, Pr, tabL, tabR, lik25, pi, col, special, lane);
+        pp_blk_load<CL, CR, BS>(B, s0, s1, it0 + BS, Lp, Rp, Lc, Rc, lane);
+        pp_blk_compute<CL, CR, BS>(A, s0, s1, it0, Pl, Pr, tabL, tabR, lik25, pi, col, special, lane);
+        pp_blk_load<CL, CR, BS>(A, s0, s1, it0 + 2 * BS, Lp, Rp, Lc, Rc, lane);
+        pp_blk_compute<CL, CR, BS>(B, s0, s1, it0 + BS, Pl, Pr, tabL, tabR, lik25, pi, col, special, lane);
     }
     return special;
 }
 
 // The same merge in its plainest form (rolled, pm_lp_mul with its rare branch), out of line: run for a particle in which some
-// site likelihood was not a positive normal number (zero, subnormal, negative, inf, NaN).  Returns the four column-group sums.
-__device__ __attribute__((noinline)) void pp_merge_slow(int S, const double* Lp, const double* Rp, const double* P /*32, LDS*/,
-                                                       const double* pi4, double* g4 /*LDS*/) {
+// site likelihood was not a positive normal number (zero, subnormal, negative, inf, NaN).  Leaves the row's sum in g[0].
+__device__ __attribute__((noinline)) void pp_merge_slow(int S, int T, const double* Lp, const double* Rp, const double* P /*32, LDS*/,
+                                                       const double* pi4, double* g /*LDS*/) {
     const int lane = threadIdx.x & 63;
-    pm_lp col[4] = {pm_lp_init(), pm_lp_init(), pm_lp_init(), pm_lp_init()};
     double Pl[16], Pr[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) { Pl[u] = P[u]; Pr[u] = P[16 + u]; }
     const double pi[4] = {pi4[0], pi4[1], pi4[2], pi4[3]};
-    const int nit = (S + 63) >> 6;
+    double tot = 0.0;
     #pragma unroll 1
-    for (int it0 = 0; it0 < nit; it0 += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s = lane + 64 * (it0 + u);
-            if (s < S) {
-                double Lv[4], Rv[4], o[4];
-                pk_load4(Lp + (size_t)s * 4, Lv);
-                pk_load4(Rp + (size_t)s * 4, Rv);
-                pk_merge_site(Lv, Rv, Pl, Pr, o);
-                pm_lp_mul(col[u], pk_site_lik(pi, o));
-            }
+    for (int s0 = 0; s0 < S; s0 += T) {
+        const int s1 = s0 + T < S ? s0 + T : S;
+        pm_lp col = pm_lp_init();
+        #pragma unroll 1
+        for (int s = s0 + lane; s < s1; s += 64) {
+            double Lv[4], Rv[4], o[4];
+            pk_load4(Lp + (size_t)s * 4, Lv);
+            pk_load4(Rp + (size_t)s * 4, Rv);
+            pk_merge_site(Lv, Rv, Pl, Pr, o);
+            pm_lp_mul(col, pk_site_lik(pi, o));
         }
+        const double t = pp_wave_tree_sum(pm_lp_finish(col));
+        tot = s0 ? tot + t : t;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const double v = pp_wave_tree_sum(pm_lp_finish(col[u]));
-        if (lane == 0) g4[u] = v;
-    }
+    if (lane == 0) g[0] = tot;
 }
 
 __device__ __forceinline__ const double* pp_node_ptr(const pp_args& a, int id) {
@@ -650,34 +636,28 @@ __device__ __forceinline__ void pp_part_b_merge(const pp_args& a, int r, int kg,
     pp_stamp(a, r, 10);
     const double (*tabL)[4] = reinterpret_cast<const double (*)[4]>(L.tab);
     const double (*tabR)[4] = reinterpret_cast<const double (*)[4]>(L.tab + 20);
-    pm_lp col[4] = {pm_lp_init(), pm_lp_init(), pm_lp_init(), pm_lp_init()};
-    bool special;
-    if (codedL) {
-        if (codedR) special = pp_merge_wave<true, true, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
-        else special = pp_merge_wave<true, false, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
-    } else {
-        if (codedR) special = pp_merge_wave<false, true, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
-        else special = pp_merge_wave<false, false, BS>(S, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
-    }
-    double g[4];
-    if (__any(special)) {                                  // rare: redo the particle with the contract's rare branch in place
-        pp_merge_slow(S, Lp, Rp, L.P, a.pi, L.tab);        // (rows are read directly: a leaf row times P equals its table entry bit
-        pp_lds_fence();                                    //  for bit; the particle's tables are no longer needed: scratch for the sums)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) g[u] = L.tab[u];
-        pp_lds_fence();
-    } else {
-        // the four column logs side by side (inlined once, after the variants: independent chains for the scheduler)
-        double v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double dE = (double)col[u].E;
-            v[u] = ((pm_log(col[u].p) + dE * 1.90821492927058770002e-10) + dE * 6.93147180369123816490e-01) + col[u].extra;
+    bool special = false;
+    double tot = 0.0;
+    #pragma unroll 1
+    for (int s0 = 0; s0 < S; s0 += a.T) {                  // tiles left to right (contract v5); primate.p: one tile
+        const int s1 = s0 + a.T < S ? s0 + a.T : S;
+        pm_lp col = pm_lp_init();
+        if (codedL) {
+            if (codedR) special |= pp_merge_wave<true, true, BS>(s0, s1, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
+            else special |= pp_merge_wave<true, false, BS>(s0, s1, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
+        } else {
+            if (codedR) special |= pp_merge_wave<false, true, BS>(s0, s1, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
+            else special |= pp_merge_wave<false, false, BS>(s0, s1, Lp, Rp, Lc, Rc, Pl, Pr, tabL, tabR, L.lik25, pi, col, lane);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) g[u] = pp_wave_tree_sum(v[u]);
+        const double t = pp_wave_tree_sum(pp_lp_finish(col));
+        tot = s0 ? tot + t : t;
     }
-    const double tot = ((g[0] + g[1]) + g[2]) + g[3];
+    if (__any(special)) {                                  // rare: redo the particle with the contract's rare branch in place
+        pp_merge_slow(S, a.T, Lp, Rp, L.P, a.pi, L.tab);   // (rows are read directly: a leaf row times P equals its table entry bit
+        pp_lds_fence();                                    //  for bit; the particle's tables are no longer needed: scratch for the sum)
+        tot = L.tab[0];
+        pp_lds_fence();
+    }
     pp_stamp(a, r, 11);
     if (lane == 0) {                                      // k8: log_likelihood_r and log w_r (vcsmc.py:376-392)
         const double fl = sum_rem + tot;

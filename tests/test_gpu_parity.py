@@ -559,3 +559,51 @@ def test_randomised_shapes_and_modes_against_the_oracle():
             assert_bit_equal(out['log_weights'][:, sl], ref['log_weights'], what)
             assert logz[i] == ref['logZ'] or (np.isnan(logz[i]) and np.isnan(ref['logZ'])), what
         assert_bit_equal(node, ref['nodes'][N - 2, Kg - 1], what + " last node")
+
+
+# ---- contract v5: the site tile of the canonical sum over sites ------------------------------------------------------
+
+@pytest.mark.parametrize("S,T,K,jc", [
+    (738, 64, 24, True),         # 12 tiles, the last one 34 sites
+    (738, 128, 24, False),       # 6 tiles
+    (449, 192, 40, False),       # tiles of three site steps, the last one 65 sites
+    (64, 64, 8, True),           # exactly one tile
+    (65, 64, 8, True),           # a second tile of one site
+    (9000, 0, 16, False),        # the default tile (2048): five tiles
+])
+def test_site_tiles_every_form_vs_oracle(S, T, K, jc):
+    """Rows longer than one tile: the merge leaves one value per (particle, tile), added left to right (pk_tile_epilogue, or in
+    the wave of the one-launch sweep and of the look-ahead potentials).  Lazy, eager, one launch and the twisted proposal,
+    each bit for bit against the C oracle run with the same tile."""
+    g = (load_dataset('primate_data_wang')['genome'][:7, :S] if S <= 738 else synthetic_alignment(9, S)['genome'])
+    N = g.shape[0]
+    Q = O.jc_Q() if jc else O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    ctx = make_ctx(g, K, Q, jc=jc)
+    assert _ffi.load().phylo_site_tile(S) == CO.site_tile(S)            # one default on both sides
+    ctx.set_site_tile(T)
+    CO.set_site_tile(T)
+    try:
+        assert ctx.site_tile() == CO.site_tile(S)
+        ref = CO.sweep(g, Q, PI, lam, lam, K, 3, jc=jc, want_nodes=True)
+        for flags in (1, 1 | 8, 1 | 32):                                # lazy, PHYLO_EAGER_NODES, PHYLO_ONE_LAUNCH
+            out = ctx.sweep(3, flags=flags)
+            np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
+            for key in ('log_likelihood', 'log_weights'):
+                assert_bit_equal(out[key], ref[key], "%s flags=%d" % (key, flags))
+            assert_bit_equal(out['logZ'], ref['logZ'], 'logZ flags=%d' % flags)
+            assert_bit_equal(ctx.sweep_node(N - 2, K - 1), ref['nodes'][N - 2, K - 1], "node")
+        if S <= 738:
+            M = 2
+            out = ctx.sweep(5, flags=1 | 2, M=M)
+            ref = CO.sweep_twisted(g, Q, PI, lam, lam, K, M, 5, jc=jc)
+            np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
+            np.testing.assert_array_equal(out['merges'], ref['merges'])
+            assert_bit_equal(out['log_weights'], ref['log_weights'], "twisted log_weights")
+            # op-level rows through the same tiles
+            core = np.random.default_rng(1).uniform(1e-3, 1.0, size=(3, 2, S, 4))
+            rec = np.array([[1, 2], [3, 1], [2, 2]], dtype=np.int32)
+            assert_bit_equal(ctx.forest_loglik(core, rec), CO.forest_loglik(PI, core, rec), "forest_loglik")
+    finally:
+        CO.set_site_tile(0)
+        ctx.close()
