@@ -13,12 +13,15 @@ What the line reports:
   t_sweep_ms            device time of ONE sweep alone (hipEvents on its stream), median of >= 20 after 3 warm-ups: the
                         reference's own usage (one evaluation sweep per epoch; training steps are sequential).
   delta_logZ_max, ancestors_equal   seeds 0..9 at the bench's K against the C oracle (the |delta log Z-hat| half of the metric).
-  roofline              the dominant kernel (the Felsenstein merge) against the resource that binds it.  With lazy nodes the
-                        launch moves ~2 % of the 96 B/unit algorithmic bytes through HBM and is bound by fp64 VALU ISSUE:
-                        frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x launch duration), instruction count from the
-                        committed rocprofv3 --pmc run at this launch shape (profiles/r02_merge_pmc.json), duration measured
-                        live with kernel-stamped HIP events.  hbm_frac = counter bytes / duration / 8 TB/s.  alg_equiv_GBps
-                        (96 B x units / duration) is an algorithmic-equivalent rate, NOT an HBM fraction.
+  roofline              the dominant kernel (the Felsenstein merge) priced by WORK: frac = achieved / peak with achieved =
+                        60 flop x particle-site-likelihoods of one launch / launch duration (SURVEY 8d's algorithmic flops:
+                        2 x (16 mul + 12 add) + 4 mul per unit; duration measured live with kernel-stamped HIP events) and peak =
+                        78.6 TFLOP/s, the vector fp64 rate (1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz = half the guide's 157.3 TFLOP/s
+                        fp32 vector peak; MFMA does not apply to 4x4 contractions).  Beside it, from the committed rocprofv3 --pmc
+                        run at this launch shape (profiles/rNN_merge_pmc.json): executed_fp64 (what the SQ_INSTS_VALU_*_F64 counters
+                        say was executed: leaf rows are table look-ups, so fewer flops are executed than the algorithm counts),
+                        valu_issue_occupancy (a DIAGNOSTIC, not a roofline: it rises when instructions are added), traffic / hbm_frac
+                        (HBM bytes from FETCH_SIZE / WRITE_SIZE: with lazy nodes ~2 % of the 96 B/unit).
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -45,7 +48,9 @@ from phylo_amd.rendezvous import exchange_comm_id  # noqa: E402
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 N_SIMD = 256 * 4           # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md)
 CLK_HZ = 2.4e9             # max clock; in-kernel s_memtime / s_memrealtime read 2.36-2.39 GHz on this workload (tests/probe_persist.py)
-VALU_ISSUE_CYCLES = 4      # a wave64 VALU instruction occupies its SIMD-32 for 4 cycles at fp64 / single-wave issue rate
+FP64_PEAK_TFLOPS = N_SIMD * 16 * 2 * CLK_HZ / 1e12   # 78.6: vector fp64 (half the guide's 157.3 TFLOP/s fp32 vector peak)
+FLOP_PER_UNIT = 60.0       # 2 x (16 mul + 12 add) + 4 mul per particle-site-likelihood (the log and the dot product not counted)
+FLOP_PER_LOOKAHEAD_UNIT = 80.0   # SURVEY 8d, twisted proposal: the merge + the pi dot product + the log-reduce of a look-ahead unit
 
 
 def parse():
@@ -66,7 +71,7 @@ def parse():
                    help='independent sweeps kept in flight on separate HIP streams (0 = 3 on one GPU, 1 when sharded)')
     p.add_argument('--batch', type=int, default=0,
                    help='independent sweeps per set of launches (phylo_sweep_batch_async); 0 = the largest divisor of --steps '
-                        'up to 10 (plain proposal, small nodes), 1 otherwise')
+                        'up to 20 (plain proposal, small nodes), 1 otherwise')
     p.add_argument('--twisting', action='store_true', help='twisted proposal (vncsmc.py); BASELINE config 2')
     p.add_argument('--M', type=int, default=1, help='sub-samples of the twisted proposal')
     p.add_argument('--params', default=None, help='.npz with Q, pi, lam_l, lam_r (e.g. trained parameters from tests/probe_regimes.py) '
@@ -176,7 +181,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     sharded_env = world > 1 or bool(os.environ.get('PHYLO_COMM_FORCE_RCCL'))
     # batching pays where launches are short (small nodes); large nodes fill the GPU with one sweep per launch set
-    batch = a.batch if a.batch > 0 else (10 if not a.twisting and S < 8192 else 1)
+    batch = a.batch if a.batch > 0 else (20 if not a.twisting and S < 8192 else 1)
     if a.batch <= 0:                                  # whole launch sets only: the largest divisor of --steps that is <= the default
         while batch > 1 and a.steps % batch:
             batch -= 1
@@ -347,30 +352,39 @@ def main():
             pass
         if pmc:
             break
-    valu_peak = N_SIMD * CLK_HZ / VALU_ISSUE_CYCLES / 1e9          # G wave-instructions / s the chip can issue
-    if pmc and pmc.get('hbm_bytes_per_launch') is not None and pmc['hbm_bytes_per_launch'] / avg_s / 1e9 > 0.5 * HBM_PEAK_GBPS:
-        bound = "hbm"
-    else:
-        bound = "valu"
-    roof = {"kernel": merge_kernel, "avg_launch_us": avg_s * 1e6, "particles_per_launch": ctx.K_local,
+    units_per_launch = float(ctx.K_local) * S
+    flops_per_launch = FLOP_PER_UNIT * units_per_launch
+    if a.twisting:
+        units_per_launch = float(ctx.K_local) * a.M * S * ((N + 1) * N * (N - 1) / 6.0) / (N - 1)   # averaged over the rank events
+        flops_per_launch = FLOP_PER_LOOKAHEAD_UNIT * units_per_launch
+    achieved = flops_per_launch / avg_s / 1e12
+    roof = {"kernel": merge_kernel, "avg_launch_us": avg_s * 1e6, "particles_per_launch": ctx.K_local, "units_per_launch": units_per_launch,
+            "bound": "valu", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+            "flop_frac": achieved / FP64_PEAK_TFLOPS,
+            "basis": ("%.0f algorithmic flop per %s (SURVEY 8d) x units per launch / live launch duration, against the vector fp64 peak "
+                      "(1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz); MFMA does not apply (4x4 contractions)"
+                      % ((FLOP_PER_LOOKAHEAD_UNIT, "look-ahead unit") if a.twisting else (FLOP_PER_UNIT, "particle-site-likelihood"))),
             "alg_bytes_per_launch": bytes_per_launch, "alg_equiv_GBps": alg_equiv,
-            "alg_equiv_note": ("64 B x look-ahead units / duration, averaged over the rank events: an algorithmic-equivalent rate, not HBM traffic"
-                               if a.twisting else
-                               "96 B x units / duration: an algorithmic-equivalent rate, not HBM traffic (lazy nodes store nothing; children are 1-byte codes or L2-resident)"),
-            "traffic": None, "hbm_frac": None, "valu_frac": None, "pmc_source": pmc['source'] if pmc else None}
+            "alg_equiv_note": "bytes of the reference's dataflow per unit x units / duration: an algorithmic-equivalent rate, NOT HBM traffic "
+                              "(lazy nodes store nothing; children are 1-byte codes or cache-resident)",
+            "traffic": None, "hbm_frac": None, "executed_fp64_TFLOPs": None, "executed_fp64_frac": None, "valu_issue_occupancy": None,
+            "pmc_source": pmc['source'] if pmc else None}
     if pmc:
         if pmc.get('hbm_bytes_per_launch') is not None:
             roof["traffic"] = pmc['hbm_bytes_per_launch']
             roof["hbm_GBps"] = pmc['hbm_bytes_per_launch'] / avg_s / 1e9
             roof["hbm_frac"] = roof["hbm_GBps"] / HBM_PEAK_GBPS
-        if pmc.get('sq_insts_valu_per_launch') is not None:
-            roof["valu_Ginstr_per_s"] = pmc['sq_insts_valu_per_launch'] / avg_s / 1e9
-            roof["valu_frac"] = roof["valu_Ginstr_per_s"] / valu_peak
-    if bound == "hbm":
-        roof.update({"bound": "hbm", "achieved": roof.get("hbm_GBps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": roof["hbm_frac"]})
-    else:
-        roof.update({"bound": "valu", "achieved": roof.get("valu_Ginstr_per_s"), "peak": valu_peak, "unit": "G wave-instr/s (fp64 VALU issue)",
-                     "frac": roof["valu_frac"]})
+        fma, add, mul = (pmc.get('sq_insts_valu_%s_f64_per_launch' % k) for k in ('fma', 'add', 'mul'))
+        if None not in (fma, add, mul):
+            roof["executed_fp64_TFLOPs"] = (2.0 * fma + add + mul) * 64.0 / avg_s / 1e12
+            roof["executed_fp64_frac"] = roof["executed_fp64_TFLOPs"] / FP64_PEAK_TFLOPS
+            if pmc.get('sq_insts_valu_per_launch') is not None:
+                f64 = fma + add + mul
+                roof["valu_issue_occupancy"] = (4.0 * f64 + 2.0 * (pmc['sq_insts_valu_per_launch'] - f64)) / (N_SIMD * CLK_HZ * avg_s)
+                roof["valu_issue_note"] = ("diagnostic only: fp64 instructions priced at 4 cycles, every other VALU instruction at 2 (a lower "
+                                           "bound: shifts, compares and DPP moves measure 4); it goes UP when instructions are added")
+        if roof["hbm_frac"] is not None and roof["hbm_frac"] > 0.5:        # eager nodes on large rows: the store stream binds
+            roof.update({"bound": "hbm", "achieved": roof["hbm_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": roof["hbm_frac"]})
 
     if rank == 0:
         units_per_step = float(K_global) * S * (N - 1)
@@ -386,14 +400,15 @@ def main():
                                       a.n_particles, K_global, N - 1),
                        "parallelism": "particles sharded over %d GPU(s), global resampling" % world,
                        "sweeps_per_launch_set": batch, "contexts_in_flight": n_streams,
-                       "sweeps_in_flight": n_streams * batch},
+                       "sweeps_in_flight": n_streams * batch, "particles_in_flight": n_streams * batch * K_global},
             "timed_region": {"repeats": len(reps_dt), "ms_total": sum(reps_dt) * 1e3, "ms_per_step_min": min(reps_dt) / a.steps * 1e3,
                              "ms_per_step_max": max(reps_dt) / a.steps * 1e3, "reported": "median repetition"},
             "t_sweep_ms": t_sweep_ms,
             "t_sweep": {"n": len(ev_ms), "min_ms": min(ev_ms), "max_ms": max(ev_ms), "timer": "hipEvents on the sweep's stream",
                         "form": "one launch (phylo_persist.h)" if a.one_launch else "launches per rank event",
                         "units_per_s": units_per_step / world / (t_sweep_ms * 1e-3),
-                        "alg_equiv_frac_of_8TBps": 96.0 * units_per_step / world / (t_sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                        "flop_frac": (FLOP_PER_UNIT * float(K_global) * S * (N - 1) + (FLOP_PER_LOOKAHEAD_UNIT * (units_per_step - float(K_global) * S * (N - 1))))
+                                     / world / (t_sweep_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
             "single_sweep_wall_ms": single_ms,
             "log_Z": last['logZ'],
             "roofline": roof,

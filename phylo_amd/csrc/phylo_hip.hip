@@ -1338,7 +1338,8 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             }
         }
         const bool nostore = (b.lazy || b.no_store) && !c->env.merge_pair_form;   // row-per-lane form when nothing is stored
-        const dim3 mgrid((unsigned)((size_t)Kl * c->ntiles));                      // one wave per (particle, site tile)
+        const size_t mitems = (size_t)Kl * c->ntiles;                              // one wave per (particle, site tile)
+        const dim3 mgrid((unsigned)mitems);
         if (timek && !twist) {  // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
             if (nostore) hipExtLaunchKernelGGL(pk_rank_merge_nostore, mgrid, dim3(64), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
             else hipExtLaunchKernelGGL(pk_rank_merge, mgrid, dim3(64), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);

@@ -1565,10 +1565,6 @@ __device__ __forceinline__ double pk_uniform(double v) {
     hi = __builtin_amdgcn_readfirstlane(hi);
     return __hiloint2double(hi, lo);
 }
-// The merge of one rank event when the new node is NOT stored (lazy nodes, the last rank event): only the node's
-// log-likelihood is needed, so the row-per-thread form applies -- thread c owns canonical column c (sites c, c+256,
-// ...), reads whole 32-byte rows (or 1-byte codes), and needs no DPP moves: about half the instructions per site of
-// the lane-pair form, whose point is the 16-byte-per-lane store.  Same fma chains, same column products: same bits.
 // ---- row loops of the merge that stores nothing (pk_rank_merge_nostore), written for VALU issue, which binds that kernel with
 //      ~24 waves per CU in flight (profiles/r02_merge_pmc.json): rows and codes are addressed as scalar base + one 32-bit offset
 //      per thread (no 64-bit address arithmetic on the vector pipe, no branch around a load), and two register sets alternate
@@ -1643,6 +1639,12 @@ __device__ __forceinline__ void pk_rows_run(int s0, int s1, const char* bl, cons
                                             const double (&pi)[4], pm_lp& col) {
     pk_rowregs B;
     int s = s0 + (int)(threadIdx.x & 63);
+    // Measured forms of this loop (20 480-particle launch, primate.p): the one below 37.7 us; both steps
+    // computed unconditionally (one padded step when the tile has an odd number of steps, validity selects on both) 41.7;
+    // the same with scheduling barriers so that B's rows travel while A is computed 40.8; four register sets, the next pair of
+    // steps in flight 39.8 (38.8 at five waves per SIMD).  hipcc sinks B's loads into B's uniform branch and waits for them
+    // there, and that is still the fastest: with seven or eight waves per SIMD the launch is bound by instruction issue, not
+    // by an exposed load, so the step and the selects that are not executed count for more than the load that is not in flight.
     #pragma unroll 1
     for (int u = s0; u < s1; u += 128, s += 128) {          // u: wave-uniform
         pk_rows_load<CL, CR>(B, bl, br, s + 64, s1);
@@ -1658,7 +1660,10 @@ __device__ __forceinline__ void pk_rows_run(int s0, int s1, const char* bl, cons
         }
     }
 }
-// one tile of one merge by one wave (a 64-thread workgroup: the barriers below are wave barriers)
+// LDS written by some lanes of a wave and read by others of the SAME wave: the LDS pipe serves a wave's instructions in
+// order, so only the compiler has to be kept from moving the reads up
+__device__ __forceinline__ void pk_wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// one tile of one merge by one wave; the tables are the wave's own slices of LDS
 template <bool CL, bool CR>
 __device__ __forceinline__ void pk_rows_loop(int s0, int s1, const double* Lp, const double* Rp, const uint8_t* Lc, const uint8_t* Rc,
                                              const double* Pu, const double* pi4, const double (&Pl)[16], const double (&Pr)[16],
@@ -1671,11 +1676,11 @@ __device__ __forceinline__ void pk_rows_loop(int s0, int s1, const double* Lp, c
     if constexpr (CL || CR) {                              // (the whole wave takes the same variant)
         if (lane < 32) pk_build_leaf_table(Pu, tabL, lane);
         else pk_build_leaf_table(Pu + 16, tabR, lane - 32);
-        __syncthreads();
+        pk_wave_lds_fence();
     }
     if constexpr (CL && CR) {
         pk_build_lik25(tabL, tabR, pi4, lik25, lane);
-        __syncthreads();
+        pk_wave_lds_fence();
     }
     pk_rows_run<CL, CR>(s0, s1, bl, br, A, Pl, Pr, tabL, tabR, lik25, pi, col);
 }
@@ -1717,11 +1722,14 @@ __device__ __forceinline__ void pk_rows_v4(int s0, int s1, const double* Xp, con
 }
 
 // The merge of one rank event when the new node is NOT stored (lazy nodes, the last rank event): one WAVE per (particle, tile),
-// grid = Kloc x ntiles workgroups of 64.  The wave's matrices, pointers and site bounds are wave-uniform (scalar registers).
+// a workgroup is one wave (two or four independent waves per workgroup measured: 1-3 % slower).  The wave's matrices, pointers
+// and site bounds are wave-uniform (scalar registers).  Row-per-lane form: lane c owns column c of the tile, reads whole 32-byte rows (or 1-byte codes), no DPP
+// moves: about half the instructions per site of the lane-pair form, whose point is the 16-byte-per-lane store.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void pk_rank_merge_nostore(const pk_rank_args a) {
     __shared__ __attribute__((aligned(16))) double tabL[5][4], tabR[5][4];
     __shared__ double lik25[25];
-    const int item = blockIdx.x, ntiles = a.ntiles, k = ntiles == 1 ? item : item / ntiles, tau = item - k * ntiles;
+    const int item = (int)blockIdx.x, ntiles = a.ntiles;
+    const int k = ntiles == 1 ? item : item / ntiles, tau = item - k * ntiles;
     const int s0 = tau * a.T, s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
     const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
     const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // wave-uniform

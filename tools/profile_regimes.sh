@@ -3,10 +3,11 @@
 # library: the "flat" workload (all-gap rows under JC69: ~63 % of the particles survive the first resampling, children spread
 # over all earlier nodes) at DS1's shape, K = 4096, one sweep per launch set, lazy and eager nodes; and primate.p with
 # trained parameters.  Three counter passes each (SQ, FETCH_SIZE, WRITE_SIZE).  tools/summarize_regimes.py reads the result.
-#   tools/profile_regimes.sh r02
+#   tools/profile_regimes.sh r03
+# synth1024_*: BASELINE config 5 at its per-GPU share (K = 8192 over 8 GPUs = 1024 particles, 208 GB node pool).
 set -uo pipefail
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$REPO/gpurun_out/prof_${TAG}_regimes
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -19,7 +20,9 @@ for cfg in "flat_lazy:--flat --dataset hohna_data_1 --n_particles 4096 --jcmodel
            "trained_lazy:--params $OUT/trained_params.npz" \
            "trained_eager:--params $OUT/trained_params.npz --eager" \
            "synth_lazy:--synthetic 128,50000 --n_particles 256" \
-           "synth_eager:--synthetic 128,50000 --n_particles 256 --eager"; do
+           "synth_eager:--synthetic 128,50000 --n_particles 256 --eager" \
+           "synth1024_lazy:--synthetic 128,50000 --n_particles 1024" \
+           "synth1024_eager:--synthetic 128,50000 --n_particles 1024 --eager"; do
   name=${cfg%%:*}; args=${cfg#*:}
   run ${name}_trace rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${name}_trace" -- python3 "$B" $COMMON $args
   run ${name}_sq rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY --output-format csv -d "$OUT/${name}_sq" -- python3 "$B" $COMMON $args

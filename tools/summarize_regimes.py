@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_%s_regimes" % tag)
 dst = os.environ.get("PROFILES_OUT") or os.path.join(ROOT, "profiles")
 N_SIMD, CLK, HBM = 1024, 2.4e9, 8.0e12
@@ -45,7 +45,10 @@ for name, what, S in (("flat_lazy", "flat 27 x 1949, K = 4096, JC69, lazy nodes"
                       ("trained_lazy", "primate.p trained parameters, K = 2048, lazy nodes", 898),
                       ("trained_eager", "primate.p trained parameters, K = 2048, eager nodes", 898),
                       ("synth_lazy", "synthetic 128 x 50 000, K = 256, lazy nodes", 50000),
-                      ("synth_eager", "synthetic 128 x 50 000, K = 256, eager nodes", 50000)):
+                      ("synth_eager", "synthetic 128 x 50 000, K = 256, eager nodes", 50000),
+                      ("synth1024_lazy", "synthetic 128 x 50 000, K = 1024 (BASELINE config 5's per-GPU share), lazy nodes", 50000),
+                      ("synth1024_eager", "synthetic 128 x 50 000, K = 1024 (BASELINE config 5's per-GPU share), eager nodes", 50000)):
+    ntiles = (S + 2047) // 2048                        # contract v5: one merge wave per (particle, tile of 2048 sites)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for d, legacy in (("sq", "trace_sq"), ("fetch", "trace_sq_fetch"), ("write", "trace_sq_fetch_write")):
         f = one("%s_%s/*/*_counter_collection.csv" % (name, d)) or one("%s_%s/*/*_counter_collection.csv" % (name, legacy))
@@ -72,7 +75,7 @@ for name, what, S in (("flat_lazy", "flat 27 x 1949, K = 4096, JC69, lazy nodes"
         fz, wz = c.get('FETCH_SIZE'), c.get('WRITE_SIZE')
         hbm = (2.0 * fz + wz) * 1024.0 if fz is not None and wz is not None else None
         us = sum(dur[key]) / len(dur[key]) if dur.get(key) else None
-        particles = key[1] if key[0].startswith('pk_rank_merge') else None
+        particles = key[1] // ntiles if key[0].startswith('pk_rank_merge') else None
         alg = 96.0 * particles * S if particles else None
         rows.append({"config": what, "kernel": key[0], "workgroups": key[1], "launches": max(len(v) for v in acc[key].values()),
                      "avg_us": us, "fetch_kb": fz, "write_kb": wz, "hbm_bytes": hbm, "alg_bytes": alg,
@@ -83,7 +86,8 @@ if rows:
     out_json["merge_launches"] = rows
     lines += ["## merge / materialise launches by regime (counters per launch; HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024)", "",
               "Durations are those of the un-countered kernel-trace pass of the same command.  A grid of the large-node kernels is",
-              "particles x site tiles, so `workgroups` is not always the particle count.", "",
+              "particles x site tiles, so `workgroups` is not always the particle count.  VALU issue frac: every VALU instruction priced at",
+              "4 cycles (an upper bound of the issue time; the primate.p table in the round summary splits fp64 from the rest).", "",
               "| configuration | kernel | workgroups | launches | avg us | FETCH KB | WRITE KB | HBM MB | algorithmic MB | HBM frac of 8 TB/s | VALU issue frac |",
               "|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
