@@ -94,7 +94,7 @@ int phylo_destroy(phylo_ctx* ctx);
 /* The arithmetic contract's site tile (contract v5): sum_s log(pi . x[s]) of compute_forest_posterior
  * (vcsmc.py:240-242) is taken tile by tile -- T sites per tile, 64 log-product columns inside a tile, tile values added left to
  * right -- so that one wavefront owns a (row, tile).  phylo_site_tile(S) is the default T for rows of S sites (the CPU oracle
- * uses the same value); phylo_set_site_tile overrides it for this context (T a positive multiple of 64; 0 = the default),
+ * uses the same value); phylo_set_site_tile overrides it for this context (T a multiple of 64 in [64, 4096]; 0 = the default),
  * which changes results in the last bits only and drops the sweep state (call it before the first sweep; PHYLO_ESTATE once a
  * communicator is set).  PHYLO_SITE_TILE=T in the environment of phylo_create does the same.  phylo_get_site_tile returns the
  * context's T. */

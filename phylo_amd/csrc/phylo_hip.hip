@@ -79,7 +79,8 @@ struct phylo_ctx {
     unsigned long long* d_rdraw = nullptr;   // [(N-1)][K] resampling draws
     unsigned long long* d_pctr = nullptr;    // [PK_MAX_GROUPS][PP_CTR_STRIDE] monotone arrival counters
     unsigned long long pctr_base = 0;        // their common value (every group receives Wg arrivals per rank event)
-    int pctr_Wg = 0;                         // workgroups per group the counters were last used with
+    int pctr_Wg = 0, pctr_G = 0;             // workgroups per group / groups the counters were last used with
+    bool pctr_dirty = false;                 // a bounded wait timed out: the counters hold partial arrivals
     int persist_blocks_per_cu = -1;          // occupancy of pp_sweep (-1: not asked yet)
     bool last_persistent = false;
     unsigned long long* d_stamps = nullptr;  // phase stamps of the one-launch sweep (PHYLO_PERSIST_STAMPS=1)
@@ -254,6 +255,9 @@ int launch_check(phylo_ctx* ctx, const char* what) {
 }
 
 void free_sweep_state(phylo_ctx* c) {
+    // the reverse pass's side streams may still read what is freed below
+    if (c->gstream) (void)hipStreamSynchronize(c->gstream);
+    if (c->bgstream) (void)hipStreamSynchronize(c->bgstream);
     if (c->d_twbuf) (void)hipFree(c->d_twbuf);
     c->d_twbuf = nullptr;
     c->twbuf_cap = 0;
@@ -299,7 +303,8 @@ void free_sweep_state(phylo_ctx* c) {
     if (c->d_pctr) (void)hipFree(c->d_pctr);
     c->d_rdraw = c->d_pctr = nullptr;
     c->pctr_base = 0;
-    c->pctr_Wg = 0;
+    c->pctr_Wg = c->pctr_G = 0;
+    c->pctr_dirty = false;
     if (c->d_tilev) (void)hipFree(c->d_tilev);
     c->d_tilev = nullptr;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse, c->d_group_seeds,
@@ -510,7 +515,7 @@ int phylo_create(const int* device_ids, int n_gpus, int K, int N, int S, int A, 
     {   // contract v5: the site tile is part of the arithmetic contract (the oracle takes the same value)
         const char* t = getenv("PHYLO_SITE_TILE");
         int T = t ? atoi(t) : pm_site_tile(S);
-        if (T < 64 || (T & 63)) { delete c; return fail(nullptr, PHYLO_EINVAL, "PHYLO_SITE_TILE must be a positive multiple of 64 (got %d)", T); }
+        if (T < 64 || (T & 63) || T > PK_MAX_SITE_TILE) { delete c; return fail(nullptr, PHYLO_EINVAL, "PHYLO_SITE_TILE must be a multiple of 64 in [64, %d] (got %d)", PK_MAX_SITE_TILE, T); }
         c->tile_override = t ? T : 0;
         c->site_tile = T;
         c->ntiles = (S + T - 1) / T;
@@ -550,6 +555,8 @@ int phylo_destroy(phylo_ctx* c) {
     if (!c) return PHYLO_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->gstream) (void)hipStreamSynchronize(c->gstream);
+    if (c->bgstream) (void)hipStreamSynchronize(c->bgstream);
     phylo_comm_destroy(&c->comm);
     free_sweep_state(c);
     void* ptrs[] = {c->d_Q, c->d_ldf, c->d_leaves, c->d_leaf_codes};
@@ -586,7 +593,8 @@ int phylo_get_site_tile(const phylo_ctx* c) { return c ? c->site_tile : 0; }
 
 int phylo_set_site_tile(phylo_ctx* c, int T) {
     CHK(bind(c));
-    if (T < 0 || (T & 63)) return fail(c, PHYLO_EINVAL, "the site tile must be a positive multiple of 64, or 0 for the default (got %d)", T);
+    if (T < 0 || (T & 63) || T > PK_MAX_SITE_TILE)
+        return fail(c, PHYLO_EINVAL, "the site tile must be a multiple of 64 in [64, %d], or 0 for the default (got %d)", PK_MAX_SITE_TILE, T);
     if (c->comm.transport != 0) return fail(c, PHYLO_ESTATE, "phylo_set_site_tile must precede phylo_comm_init (peers map the sweep state)");
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tile_override = T;
@@ -1081,14 +1089,16 @@ static int sweep_persistent(phylo_ctx* c, uint64_t seed, uint32_t flags, const u
     if (!c->d_rdraw) CHK(dalloc(c, &c->d_rdraw, (size_t)R * K));       // (the launch path's pk_rank_book_mat shares this buffer)
     if (!c->d_pctr) {
         CHK(dalloc(c, &c->d_pctr, (size_t)PK_MAX_GROUPS * PP_CTR_STRIDE));
-        HIPCHK(c, hipMemsetAsync(c->d_pctr, 0, (size_t)PK_MAX_GROUPS * PP_CTR_STRIDE * 8, c->stream));
-        c->pctr_base = 0;
-        c->pctr_Wg = Wg;
+        c->pctr_Wg = 0;
     }
-    if (c->pctr_Wg != Wg) {                                // another grid shape: restart the monotone counters
+    // Every group owns one monotone counter and expects it to equal ctr_base at launch.  Another grid shape, another number of
+    // groups (the groups the previous launches did not use are behind) or a timed-out wait (partial arrivals): start again from 0.
+    if (c->pctr_Wg != Wg || c->pctr_G != G || c->pctr_dirty) {
         HIPCHK(c, hipMemsetAsync(c->d_pctr, 0, (size_t)PK_MAX_GROUPS * PP_CTR_STRIDE * 8, c->stream));
         c->pctr_base = 0;
         c->pctr_Wg = Wg;
+        c->pctr_G = G;
+        c->pctr_dirty = false;
     }
     pp_args a{};
     a.N = N; a.S = S; a.K = K; a.Kg = Kg; a.G = G; a.R = R; a.Wg = Wg; a.m = m;
@@ -1250,7 +1260,6 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             ta.bl_r = c->d_bl + (size_t)r * Kl; ta.br_r = c->d_br + (size_t)r * Kl;
             ta.own_tables = c->comm.transport == 0 ? 1 : 0;
             ta.wbuf = c->d_twbuf;
-            const size_t rowlist_lds = (((size_t)(N - r - 1) * M * 2) + 15) & ~(size_t)15;
             hipLaunchKernelGGL(pk_twist_adopt_draws, dim3(K + cdiv(2L * Kl * ta.J, 64)), dim3(64), 0, c->stream, ta, (const double*)c->d_Q, c->jc);
             CHK(launch_check(c, "pk_twist_adopt_draws"));
             if (ta.pair_hist) {                            // coded leaf-leaf pairs: 25 code pairs per row instead of S sites
@@ -1258,11 +1267,15 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
                 CHK(launch_check(c, "pk_twist_potentials_ll"));
                 ++launches;
             }
-            if (timek)     // a twisted sweep's dominant kernel is this one: PHYLO_TIME_KERNELS stamps it instead of the merge
-                hipExtLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((((size_t)Kl * (N - r - 1) + 7) / 8) * 8)), dim3(PK_COLS), rowlist_lds, c->stream,
-                                      c->kev[2 * r], c->kev[2 * r + 1], 0, ta);
-            else
-                hipLaunchKernelGGL(pk_twist_potentials, dim3((unsigned)((((size_t)Kl * (N - r - 1) + 7) / 8) * 8)), dim3(PK_COLS), rowlist_lds, c->stream, ta);
+            // every other row: one wave each (at rank event 0 of a coded alignment every root is a leaf: nothing is left)
+            const bool any_rows = !(ta.pair_hist && r == 0);
+            const dim3 pgrid((unsigned)((((size_t)Kl * ta.J + 7) / 8) * 8));
+            if (timek) {   // a twisted sweep's dominant kernel is this one: PHYLO_TIME_KERNELS stamps it instead of the merge
+                if (any_rows) hipExtLaunchKernelGGL(pk_twist_potentials, pgrid, dim3(64), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, ta);
+                else { HIPCHK(c, hipEventRecord(c->kev[2 * r], c->stream)); HIPCHK(c, hipEventRecord(c->kev[2 * r + 1], c->stream)); }
+            } else if (any_rows) {
+                hipLaunchKernelGGL(pk_twist_potentials, pgrid, dim3(64), 0, c->stream, ta);
+            }
             CHK(launch_check(c, "pk_twist_potentials"));
             hipLaunchKernelGGL(pk_twist_choose, dim3(Kl), dim3(64), (size_t)(ta.J <= PK_TWIST_LDS_J ? ta.J : 0) * 8, c->stream, ta);
             CHK(launch_check(c, "pk_twist_choose"));
@@ -1342,11 +1355,11 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
         const dim3 mgrid((unsigned)mitems);
         if (timek && !twist) {  // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
             if (nostore) hipExtLaunchKernelGGL(pk_rank_merge_nostore, mgrid, dim3(64), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
-            else hipExtLaunchKernelGGL(pk_rank_merge, mgrid, dim3(64), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
+            else hipExtLaunchKernelGGL(pk_rank_merge, mgrid, dim3(PK_COLS), (size_t)(c->site_tile < S ? c->site_tile : S) * 8, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
         } else if (nostore) {
             hipLaunchKernelGGL(pk_rank_merge_nostore, mgrid, dim3(64), 0, c->stream, b);
         } else {
-            hipLaunchKernelGGL(pk_rank_merge, mgrid, dim3(64), 0, c->stream, b);
+            hipLaunchKernelGGL(pk_rank_merge, mgrid, dim3(PK_COLS), (size_t)(c->site_tile < S ? c->site_tile : S) * 8, c->stream, b);
         }
         if (c->ntiles > 1) {    // rows longer than one tile: tile values left to right, then the particle's weight terms
             CHK(launch_check(c, "pk_rank_merge"));
@@ -1519,12 +1532,15 @@ int phylo_sweep_batch_async(phylo_ctx* c, const uint64_t* seeds, int G, uint32_t
     return phylo_sweep_finish(c);
 }
 
+static int check_timeout_word(phylo_ctx* c, bool pub);
+
 int phylo_sweep_fetch_logz(phylo_ctx* c, double* logZ, int G) {
     CHK(bind(c));
     if (!c->swept) return fail(c, PHYLO_ESTATE, "no sweep has been run");
     if (!logZ || G != c->last_G) return fail(c, PHYLO_EINVAL, "the last sweep batched %d sweep(s), asked for %d", c->last_G, G);
     const size_t R = (size_t)c->N - 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    CHK(check_timeout_word(c, false));
     std::vector<double> all((R + 1) * G);
     HIPCHK(c, hipMemcpy(all.data(), c->d_lse, all.size() * 8, hipMemcpyDeviceToHost));
     for (int g = 0; g < G; ++g) logZ[g] = all[g * (R + 1) + R];
@@ -1537,6 +1553,20 @@ int phylo_synchronize(phylo_ctx* c) {
     return PHYLO_OK;
 }
 
+// The word every bounded wait between workgroups sets when it gives up (one-launch sweep, fused scan + bookkeeping): a sweep that
+// timed out is invalid.  The stream must be idle.  `pub`: the sweep's copy kernel left the word in pinned memory.
+static int check_timeout_word(phylo_ctx* c, bool pub) {
+    unsigned int tmo = 0;
+    if (pub) tmo = c->h_pub[2];
+    else HIPCHK(c, hipMemcpy(&tmo, c->d_counter + 1, sizeof tmo, hipMemcpyDeviceToHost));
+    if (tmo) {
+        HIPCHK(c, hipMemset(c->d_counter + 1, 0, sizeof tmo));
+        c->pctr_dirty = true;                              // the one-launch sweep's arrival counters hold partial arrivals
+        return fail(c, PHYLO_EHIP, "a bounded wait between workgroups timed out inside a launch; results are invalid");
+    }
+    return PHYLO_OK;
+}
+
 int phylo_sweep_fetch(phylo_ctx* c, double* log_weights, double* log_lik, double* lbranch, double* rbranch,
                       int32_t* merges, int64_t* ancestors, double* logZ, phylo_stats* perf) {
     CHK(bind(c));
@@ -1544,15 +1574,7 @@ int phylo_sweep_fetch(phylo_ctx* c, double* log_weights, double* log_lik, double
     const size_t R = (size_t)c->N - 1, K = c->K, Kl = c->Kloc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const bool pub = c->last_graph && c->h_pub;            // the sweep kept its graph: its copy kernel left these in pinned memory
-    {
-        unsigned int tmo = 0;
-        if (pub) tmo = c->h_pub[2];
-        else HIPCHK(c, hipMemcpy(&tmo, c->d_counter + 1, sizeof tmo, hipMemcpyDeviceToHost));
-        if (tmo) {
-            HIPCHK(c, hipMemset(c->d_counter + 1, 0, sizeof tmo));
-            return fail(c, PHYLO_EHIP, "a bounded wait between workgroups timed out inside a launch; results are invalid");
-        }
-    }
+    CHK(check_timeout_word(c, pub));
     // log_weights / log_lik are stored with global columns; hand back this rank's columns
     if (Kl == K) {                      // one rank: rows are contiguous
         if (log_weights) HIPCHK(c, hipMemcpy(log_weights, c->d_logw, R * K * 8, hipMemcpyDeviceToHost));
@@ -1626,7 +1648,22 @@ int phylo_sweep_node(phylo_ctx* c, int r, int k, double* out) {
     return PHYLO_OK;
 }
 
+static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q, phylo_stats* perf);
+
 int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q, phylo_stats* perf) {
+    const int rc = sweep_backward_impl(c, d_lam_l, d_lam_r, d_pi, d_Q, perf);
+    if (rc != PHYLO_OK && c) {
+        // an early return may have left kernels on the side streams that still read the pinned list image and the graph: join them
+        // before anything rebuilds or frees those, and drop the graph (the next backward needs a new sweep)
+        if (c->gstream) (void)hipStreamSynchronize(c->gstream);
+        if (c->bgstream) (void)hipStreamSynchronize(c->bgstream);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        c->last_graph = false;
+    }
+    return rc;
+}
+
+static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q, phylo_stats* perf) {
     CHK(bind(c));
     if (!c->swept || !c->last_graph)
         return fail(c, PHYLO_ESTATE, "phylo_sweep_backward needs a preceding sweep with PHYLO_KEEP_GRAPH");

@@ -1235,17 +1235,19 @@ __global__ __launch_bounds__(PK_COLS) void pk_rank_scan_book(const pk_rank_args 
 }
 
 // ------------------------------------------------------------------------------------------------
-// The Felsenstein merge of one rank event, one WAVE per (local particle, site tile); grid = Kloc x ntiles workgroups of 64.
+// The Felsenstein merge of one rank event in the form that STORES the node: one workgroup of 256 threads per (local particle,
+// site tile); grid = Kloc x ntiles.
 //   k2: the new node's partial likelihoods, out[s,:] = (L[s,:] P_l) * (R[s,:] P_r)      (vcsmc.py:185-187)
 //   k3: sum_s log(pi . out[s,:]) in the canonical order                                  (vcsmc.py:240-242)
 //   k8: log_likelihood_r and log w_r                                                     (vcsmc.py:376-392)
-// Half-row form (the form that STORES the node): a lane PAIR owns a site.  Lane parity h loads the 16 bytes holding states
-// 2h, 2h+1 of each child (so a wave reads 1 KiB contiguous per instruction from the [K x S x 4] tensor), completes the rows
-// with DPP quad_perm moves, produces output states 2h, 2h+1 and stores its 16 bytes (non-temporal: only the
-// few particles that survive the next resampling ever read the node again).  Per 64-site step pair p takes
-// two sites, s0 + p + 64 q (-> column p of the tile, finished on the even lane) and s0 + p + 32 + 64 q (-> column
-// p + 32, odd lane), so every lane runs exactly one log per tile.  Arithmetic per output state is the same
-// fma chain as pk_merge_site: results are bit-identical to the row-per-thread form.
+// Phase 1, all four waves (what bounds this kernel is the store stream, so the rows are spread over as many waves as the
+// old 256-column form had): a lane PAIR owns a site.  Lane parity h loads the 16 bytes holding states 2h, 2h+1 of each child
+// (a wave reads 1 KiB contiguous per instruction from the [K x S x 4] tensor), completes the rows with DPP quad_perm moves,
+// produces output states 2h, 2h+1 and stores its 16 bytes (non-temporal: only the few particles that survive the next
+// resampling ever read the node again); the site's likelihood pi . out goes to LDS.  128 sites per step.
+// Phase 2, wave 0: the tile's 64 column products (contract v5: lane = column, sites in increasing order, read back from LDS),
+// one log per lane, the tree, the epilogue.  Arithmetic per output state is the same fma chain as pk_merge_site: results are
+// bit-identical to the row-per-lane form.
 //   algorithmic traffic: 2 x 32 B read + 32 B written per (particle, site) = 96 B / unit.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double pk_dpp_even(double v) {   // the value held by the even lane of my pair
@@ -1284,79 +1286,65 @@ __device__ __forceinline__ void pk_build_leaf_table(const double* __restrict__ P
     }
 }
 
-// sites [s0, s1) of one tile by one wave; lane = 2 p + h
+// sites [s0, s1) of one tile by one workgroup; thread = 2 p + h, pair p owns sites s0 + p + 128 q
 template <bool CL, bool CR, bool STORE>
 __device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, int s0, int s1, const double* Lp, const double* Rp,
                                               const uint8_t* Lc, const uint8_t* Rc, double* out,
                                               const double (&Plc)[4][2], const double (&Prc)[4][2],
-                                              const double (*tabL)[4], const double (*tabR)[4], pm_lp& col, int p, int h) {
+                                              const double (*tabL)[4], const double (*tabR)[4], double* likbuf, int p, int h) {
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     // software pipeline: the next step's rows (or codes) are fetched before this step is computed
-    pk_d2 nla = {0, 0}, nra = {0, 0}, nlb = {0, 0}, nrb = {0, 0};
-    int ncla = 0, ncra = 0, nclb = 0, ncrb = 0;
+    pk_d2 nl = {0, 0}, nr = {0, 0};
+    int ncl = 0, ncr = 0;
     if (s0 + p < s1) {
-        if (CL) ncla = Lc[s0 + p]; else nla = pk_gload2(Lp + (size_t)(s0 + p) * 4);
-        if (CR) ncra = Rc[s0 + p]; else nra = pk_gload2(Rp + (size_t)(s0 + p) * 4);
+        if (CL) ncl = Lc[s0 + p]; else nl = pk_gload2(Lp + (size_t)(s0 + p) * 4);
+        if (CR) ncr = Rc[s0 + p]; else nr = pk_gload2(Rp + (size_t)(s0 + p) * 4);
     }
-    if (s0 + p + 32 < s1) {
-        if (CL) nclb = Lc[s0 + p + 32]; else nlb = pk_gload2(Lp + (size_t)(s0 + p + 32) * 4);
-        if (CR) ncrb = Rc[s0 + p + 32]; else nrb = pk_gload2(Rp + (size_t)(s0 + p + 32) * 4);
-    }
-    const int nq = (s1 - s0 + 63) >> 6;
+    const int nq = (s1 - s0 + 127) >> 7;
     for (int q = 0; q < nq; ++q) {
-        const int sa = s0 + p + 64 * q, sb = sa + 32;
-        const bool va = sa < s1, vb = sb < s1;
-        const pk_d2 la = nla, ra = nra, lb = nlb, rb = nrb;
-        const int cla = ncla, cra = ncra, clb = nclb, crb = ncrb;
-        if (sa + 64 < s1) {
-            if (CL) ncla = Lc[sa + 64]; else nla = pk_gload2(Lp + (size_t)(sa + 64) * 4);
-            if (CR) ncra = Rc[sa + 64]; else nra = pk_gload2(Rp + (size_t)(sa + 64) * 4);
+        const int s = s0 + p + 128 * q;
+        const bool valid = s < s1;
+        const pk_d2 l2 = nl, r2 = nr;
+        const int cl = ncl, cr = ncr;
+        if (s + 128 < s1) {
+            if (CL) ncl = Lc[s + 128]; else nl = pk_gload2(Lp + (size_t)(s + 128) * 4);
+            if (CR) ncr = Rc[s + 128]; else nr = pk_gload2(Rp + (size_t)(s + 128) * 4);
         }
-        if (sb + 64 < s1) {
-            if (CL) nclb = Lc[sb + 64]; else nlb = pk_gload2(Lp + (size_t)(sb + 64) * 4);
-            if (CR) ncrb = Rc[sb + 64]; else nrb = pk_gload2(Rp + (size_t)(sb + 64) * 4);
+        double lp[2], rp[2];
+        if (CL) {
+            const pk_d2 v = *reinterpret_cast<const pk_d2*>(&tabL[cl][2 * h]);      // one ds_read_b128
+            lp[0] = v.x; lp[1] = v.y;
+        } else {
+            const double L[4] = {pk_dpp_even(l2.x), pk_dpp_even(l2.y), pk_dpp_odd(l2.x), pk_dpp_odd(l2.y)};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                double v = L[0] * Plc[0][c];
+                v = pm_fma(L[1], Plc[1][c], v);
+                v = pm_fma(L[2], Plc[2][c], v);
+                lp[c] = pm_fma(L[3], Plc[3][c], v);
+            }
         }
-        double lik[2];
+        if (CR) {
+            const pk_d2 v = *reinterpret_cast<const pk_d2*>(&tabR[cr][2 * h]);
+            rp[0] = v.x; rp[1] = v.y;
+        } else {
+            const double R[4] = {pk_dpp_even(r2.x), pk_dpp_even(r2.y), pk_dpp_odd(r2.x), pk_dpp_odd(r2.y)};
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const pk_d2 l2 = t ? lb : la, r2 = t ? rb : ra;
-            const int cl = t ? clb : cla, cr = t ? crb : cra;
-            double lp[2], rp[2];
-            if (CL) {
-                const pk_d2 v = *reinterpret_cast<const pk_d2*>(&tabL[cl][2 * h]);      // one ds_read_b128
-                lp[0] = v.x; lp[1] = v.y;
-            } else {
-                const double L[4] = {pk_dpp_even(l2.x), pk_dpp_even(l2.y), pk_dpp_odd(l2.x), pk_dpp_odd(l2.y)};
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    double v = L[0] * Plc[0][c];
-                    v = pm_fma(L[1], Plc[1][c], v);
-                    v = pm_fma(L[2], Plc[2][c], v);
-                    lp[c] = pm_fma(L[3], Plc[3][c], v);
-                }
+            for (int c = 0; c < 2; ++c) {
+                double v = R[0] * Prc[0][c];
+                v = pm_fma(R[1], Prc[1][c], v);
+                v = pm_fma(R[2], Prc[2][c], v);
+                rp[c] = pm_fma(R[3], Prc[3][c], v);
             }
-            if (CR) {
-                const pk_d2 v = *reinterpret_cast<const pk_d2*>(&tabR[cr][2 * h]);
-                rp[0] = v.x; rp[1] = v.y;
-            } else {
-                const double R[4] = {pk_dpp_even(r2.x), pk_dpp_even(r2.y), pk_dpp_odd(r2.x), pk_dpp_odd(r2.y)};
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    double v = R[0] * Prc[0][c];
-                    v = pm_fma(R[1], Prc[1][c], v);
-                    v = pm_fma(R[2], Prc[2][c], v);
-                    rp[c] = pm_fma(R[3], Prc[3][c], v);
-                }
-            }
-            const double o[2] = {lp[0] * rp[0], lp[1] * rp[1]};
-            if (STORE && (t ? vb : va)) {
-                const pk_d2 ov = {o[0], o[1]};
-                __builtin_nontemporal_store(ov, reinterpret_cast<pk_d2*>(out + (size_t)(t ? sb : sa) * 4));
-            }
-            const double f[4] = {pk_dpp_even(o[0]), pk_dpp_even(o[1]), pk_dpp_odd(o[0]), pk_dpp_odd(o[1])};
-            lik[t] = pk_site_lik(pi, f);
         }
-        if (h ? vb : va) pm_lp_mul(col, h ? lik[1] : lik[0]);
+        const double o[2] = {lp[0] * rp[0], lp[1] * rp[1]};
+        if (STORE && valid) {
+            const pk_d2 ov = {o[0], o[1]};
+            __builtin_nontemporal_store(ov, reinterpret_cast<pk_d2*>(out + (size_t)s * 4));
+        }
+        const double f[4] = {pk_dpp_even(o[0]), pk_dpp_even(o[1]), pk_dpp_odd(o[0]), pk_dpp_odd(o[1])};
+        const double lik = pk_site_lik(pi, f);
+        if (valid && h == 0) likbuf[s - s0] = lik;
     }
 }
 
@@ -1382,14 +1370,15 @@ __global__ __launch_bounds__(256) void pk_tile_epilogue(const pk_rank_args a) {
     pk_merge_epilogue(a, k, a.k0 + k, tot);
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void pk_rank_merge(const pk_rank_args a) {
-    __shared__ double cols[64];
+#define PK_MAX_SITE_TILE 4096            // the storing merge keeps a tile's site likelihoods in LDS (8 bytes each)
+__global__ __launch_bounds__(PK_COLS, 5) void pk_rank_merge(const pk_rank_args a) {
+    extern __shared__ __attribute__((aligned(16))) double pk_likbuf[];        // [T] site likelihoods of this tile
     __shared__ __attribute__((aligned(16))) double tabL[5][4], tabR[5][4];
     const int item = blockIdx.x, k = a.ntiles == 1 ? item : item / a.ntiles, tau = item - k * a.ntiles;
-    const int kg = a.k0 + k, lane = threadIdx.x, p = lane >> 1, h = lane & 1;
+    const int kg = a.k0 + k, tid = threadIdx.x, p = tid >> 1, h = tid & 1;
     const int s0 = tau * a.T, s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
     const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
-    const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // wave-uniform
+    const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // workgroup-uniform
     const double* Lp = pk_node_ptr(a, cl) + 2 * h;
     const double* Rp = pk_node_ptr(a, cr) + 2 * h;
     const uint8_t* Lc = a.leaf_codes + (codedL ? (size_t)cl * a.S : 0);
@@ -1405,25 +1394,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     }
     if (codedL || codedR) {
         const double* Pu = a.Pmat + (size_t)k * 32;
-        if (lane < 32) pk_build_leaf_table(Pu, tabL, lane);
-        else pk_build_leaf_table(Pu + 16, tabR, lane - 32);
+        if (tid < 32) pk_build_leaf_table(Pu, tabL, tid);
+        else if (tid < 64) pk_build_leaf_table(Pu + 16, tabR, tid - 32);
         __syncthreads();
     }
-    pm_lp col = pm_lp_init();
-#define PK_MERGE_DISPATCH(ST)                                                                                      \
-    if (codedL) {                                                                                                  \
-        if (codedR) pk_merge_body<true, true, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);   \
-        else pk_merge_body<true, false, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);         \
-    } else {                                                                                                       \
-        if (codedR) pk_merge_body<false, true, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);  \
-        else pk_merge_body<false, false, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, col, p, h);        \
+#define PK_MERGE_DISPATCH(ST)                                                                                           \
+    if (codedL) {                                                                                                       \
+        if (codedR) pk_merge_body<true, true, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, pk_likbuf, p, h);   \
+        else pk_merge_body<true, false, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, pk_likbuf, p, h);         \
+    } else {                                                                                                            \
+        if (codedR) pk_merge_body<false, true, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, pk_likbuf, p, h);  \
+        else pk_merge_body<false, false, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, pk_likbuf, p, h);        \
     }
     if (a.lazy || a.no_store) { PK_MERGE_DISPATCH(false) } else { PK_MERGE_DISPATCH(true) }
 #undef PK_MERGE_DISPATCH
-    cols[p + 32 * h] = pm_lp_finish(col);           // lane (p, h) owns column p + 32 h of the tile
     __syncthreads();
-    const double tot = pk_wave_tree_sum(cols[lane]);
-    if (lane == 0) {
+    if (tid >= 64) return;
+    // phase 2: lane = column of the tile; the column's sites in increasing order, two per renormalisation
+    pm_lp col = pm_lp_init();
+    const int len = s1 - s0;
+    for (int j = tid; j < len; j += 128) {
+        const double xa = pk_likbuf[j];
+        if (j + 64 < len) pm_lp_mul2(col, xa, pk_likbuf[j + 64]);
+        else pm_lp_mul(col, xa);
+    }
+    const double tot = pk_wave_tree_sum(pm_lp_finish(col));
+    if (tid == 0) {
         if (a.ntiles == 1) pk_merge_epilogue(a, k, kg, tot);
         else a.tilev[(size_t)k * a.ntiles + tau] = tot;
     }
@@ -1554,9 +1550,6 @@ __device__ __forceinline__ void pk_twist_row_cc(int s0, int s1, const uint8_t* L
     }
 }
 
-// pk_twist_potentials (below): one workgroup per (local particle, left root r1): all pairs (r1, r2 > r1) x M sub-samples,
-// one WAVE per (pair, sub-sample) row at a time (lane = column of the site tile).  Nothing is stored but the potentials.
-// fp64-VALU bound (about 80 flops per particle-site-pair).
 // force a wave-uniform value into scalar registers (the compiler keeps uniform loads in VGPRs once the
 // kernel has stored to global memory)
 __device__ __forceinline__ double pk_uniform(double v) {
@@ -1839,132 +1832,98 @@ __global__ __launch_bounds__(256) void pk_twist_potentials_ll(const pk_twist_arg
     }
 }
 
-__global__ __launch_bounds__(PK_COLS, 5) void pk_twist_potentials(const pk_twist_args ta) {
-    __shared__ __attribute__((aligned(16))) double Psh[PK_TWIST_LDS_ROWS][32];
-    __shared__ __attribute__((aligned(16))) double tab[PK_TWIST_LDS_ROWS][2][5][4];
-    __shared__ __attribute__((aligned(16))) double vsh[PK_TWIST_LDS_ROWS][5][4];   // contract v4 tables of the staged rows
-    extern __shared__ __attribute__((aligned(16))) char pk_tw_dyn[];   // dynamic: 2 ((n-1) M rounded up) bytes
-    short* rowlist = reinterpret_cast<short*>(pk_tw_dyn);
-    __shared__ int nlist;
+// Look-ahead potentials, one WAVE per (particle, pair, sub-sample) row: grid = Kloc * J workgroups of 64 (rounded up to a
+// multiple of 8), no workgroup barrier, no staging shared between rows.  (Until round 3 a workgroup owned a (particle, left root)
+// and staged eight rows' matrices and tables at a time behind barriers: 76 % of its wave cycles were waits.)  Rows of two coded
+// leaves leave at once (pk_twist_potentials_ll prices them by code pair).
+//   coded leaf x internal root (contract v4): the wave builds the five vectors v_c in its LDS slice (20 lanes), then X[s] . v_code
+//   everything else: the merge's row loops (pk_rows_run) with both matrices in scalar registers
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void pk_twist_potentials(const pk_twist_args ta) {
+    __shared__ __attribute__((aligned(16))) double tab[2][5][4];
+    __shared__ __attribute__((aligned(16))) double vtab[5][4];
     const pk_rank_args& a = ta.a;
-    const int n = a.n, M = ta.M, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of particles, so that the
-    // n-1 workgroups of a particle (which read the same internal roots) share one L2.  gridDim.x is a multiple of 8.
-    const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if (bid >= a.Kloc * (n - 1)) return;
-    const int k = bid / (n - 1), r1 = bid - k * (n - 1), kg = a.k0 + k;
+    const int n = a.n, M = ta.M, J = ta.J, lane = threadIdx.x;
+    // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of rows, i.e. of particles, so that the
+    // rows of a particle (which read the same internal roots) share one L2.  gridDim.x is a multiple of 8.
+    const long nitems = (long)a.Kloc * J;
+    const long bid = (long)(blockIdx.x & 7) * (long)(gridDim.x >> 3) + (long)(blockIdx.x >> 3);
+    if (bid >= nitems) return;
+    const int k = (int)(bid / J), j = (int)(bid - (long)k * J), kg = a.k0 + k;
+    int r1 = 0, rem = j / M;                                   // pair t = j / M, lexicographic (r1 < r2)
+    while (rem >= n - 1 - r1) { rem -= n - 1 - r1; ++r1; }
+    const int r2 = r1 + 1 + rem;
     const int32_t* ro = ta.roots_ad + (size_t)kg * a.N;
-    const int32_t* co = ta.cnt_ad + (size_t)kg * a.N;
-    const double* rl = ta.rootll_ad + (size_t)kg * a.N;
-    const int idl = ro[r1];
+    const int idl = ro[r1], idr = ro[r2];
+    const bool leafL = idl < a.N, leafR = idr < a.N;
+    if (ta.pair_hist && leafL && leafR) return;                // coded leaf x coded leaf: pk_twist_potentials_ll
+    const double* P = ta.tw_P + ((size_t)k * J + j) * 32;      // wave-uniform: scalar loads
     const double* Lp = pk_node_ptr(a, idl);
-    const bool cL = a.leaf_codes && idl < a.N;           // workgroup-uniform
+    const double* Rp = pk_node_ptr(a, idr);
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
-    // pair index of (r1, r1+1): sum_{i<r1} (n-1-i)
-    const int t0 = r1 * (n - 1) - r1 * (r1 - 1) / 2;
-    const int nrows_all = (n - 1 - r1) * M;              // rows of this workgroup: (r2 - r1 - 1) * M + m
-    // rows left for this kernel: everything but the coded leaf-leaf pairs (pk_twist_potentials_ll)
-    const bool llL = ta.pair_hist && idl < a.N;
-    if (!llL) {
-        for (int i = tid; i < nrows_all; i += PK_COLS) rowlist[i] = (short)i;
-        if (tid == 0) nlist = nrows_all;
-    } else if (tid < 64) {                               // wave 0 compacts in row order
-        int base = 0;
-        for (int i0 = 0; i0 < nrows_all; i0 += 64) {
-            const int i = i0 + tid;
-            const bool keep = i < nrows_all && ro[r1 + 1 + i / M] >= a.N;
-            const unsigned long long m = __ballot(keep);
-            if (keep) rowlist[base + __popcll(m & ((1ull << tid) - 1ull))] = (short)i;
-            base += __popcll(m);
+    double tot = 0.0;
+    if (ta.codes && leafL != leafR) {                          // contract v4
+        if (lane < 20) {
+            const int c = lane >> 2, ii = lane & 3;
+            const double* Pleaf = P + (leafL ? 0 : 16);
+            const double* Pint = P + (leafL ? 16 : 0);
+            double acc = Pint[ii * 4] * (pi[0] * pk_leaf_entry(Pleaf, c, 0));
+            acc = pm_fma(Pint[ii * 4 + 1], pi[1] * pk_leaf_entry(Pleaf, c, 1), acc);
+            acc = pm_fma(Pint[ii * 4 + 2], pi[2] * pk_leaf_entry(Pleaf, c, 2), acc);
+            vtab[c][ii] = pm_fma(Pint[ii * 4 + 3], pi[3] * pk_leaf_entry(Pleaf, c, 3), acc);
         }
-        if (tid == 0) nlist = base;
-    }
-    __syncthreads();
-    const int nrows = nlist;
-    const double* Pblock = ta.tw_P + ((size_t)k * ta.J + (size_t)t0 * M) * 32;   // rows are contiguous in j
-    for (int base = 0; base < nrows; base += PK_TWIST_LDS_ROWS) {
-        const int cnt = nrows - base < PK_TWIST_LDS_ROWS ? nrows - base : PK_TWIST_LDS_ROWS;
-        // stage the transition matrices of this pass and the leaf lookup tables built from them: one global
-        // round trip per pass instead of one per row
-        for (int i = tid; i < cnt * 32; i += PK_COLS) Psh[i >> 5][i & 31] = Pblock[(size_t)rowlist[base + (i >> 5)] * 32 + (i & 31)];
-        __syncthreads();
-        for (int i = tid; i < cnt * 40; i += PK_COLS) {
-            const int q = i / 40, e = i - q * 40, side = e / 20;
-            pk_build_leaf_table(&Psh[q][side * 16], tab[q][side], e - side * 20);
+        pk_wave_lds_fence();
+        const double* Xp = leafL ? Rp : Lp;
+        const uint8_t* cd = ta.codes + (size_t)(leafL ? idl : idr) * a.S;
+        for (int s0 = 0; s0 < a.S; s0 += a.T) {
+            const int s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
+            pm_lp col = pm_lp_init();
+            pk_rows_v4(s0, s1, Xp, cd, vtab, col);
+            const double t = pk_wave_tree_sum(pm_lp_finish(col));
+            tot = s0 ? tot + t : t;
         }
-        __syncthreads();
-        if (ta.codes) {                                   // v4 tables of the rows with exactly one leaf
-            const bool leafL = idl < a.N;
-            for (int i = tid; i < cnt * 20; i += PK_COLS) {
-                const int q = i / 20, e = i - q * 20, c = e >> 2, ii = e & 3;
-                const bool leafR = ro[r1 + 1 + rowlist[base + q] / M] < a.N;
-                if (leafL == leafR) continue;
-                const double (*tl)[4] = tab[q][leafL ? 0 : 1];            // (leaf row of code c) . P_leaf
-                const double* Pint = &Psh[q][leafL ? 16 : 0];            // the internal root's matrix
-                double acc = Pint[ii * 4] * (pi[0] * tl[c][0]);
-                acc = pm_fma(Pint[ii * 4 + 1], pi[1] * tl[c][1], acc);
-                acc = pm_fma(Pint[ii * 4 + 2], pi[2] * tl[c][2], acc);
-                vsh[q][c][ii] = pm_fma(Pint[ii * 4 + 3], pi[3] * tl[c][3], acc);
-            }
-            __syncthreads();
-        }
-        // contract v5: one WAVE per (pair, sub-sample) row, lane = column of the tile, tiles left to right; no barrier, no LDS
-        // between a row's sites and its potential
-        for (int q = wv; q < cnt; q += 4) {
-            const int row = rowlist[base + q], r2 = r1 + 1 + row / M;
-            const int idr = ro[r2];
-            const double* Rp = pk_node_ptr(a, idr);
-            double tot = 0.0;
-            if (ta.codes && ((idl < a.N) != (idr < a.N))) {                    // coded leaf x internal root: contract v4
-                const double* Xp = idl < a.N ? Rp : Lp;
-                const uint8_t* cd = ta.codes + (size_t)(idl < a.N ? idl : idr) * a.S;
-                for (int s0 = 0; s0 < a.S; s0 += a.T) {
-                    const int s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
-                    pm_lp col = pm_lp_init();
-                    pk_rows_v4(s0, s1, Xp, cd, vsh[q], col);
-                    const double t = pk_wave_tree_sum(pm_lp_finish(col));
-                    tot = s0 ? tot + t : t;
-                }
-            } else {
-                const bool cR = a.leaf_codes && idr < a.N;
-                const uint8_t* Lc = a.leaf_codes + (cL ? (size_t)idl * a.S : 0);
-                const uint8_t* Rc = a.leaf_codes + (cR ? (size_t)idr * a.S : 0);
-                double Pl[16], Pr[16];
+    } else {
+        const bool cL = a.leaf_codes && leafL, cR = a.leaf_codes && leafR;
+        const uint8_t* Lc = a.leaf_codes + (cL ? (size_t)idl * a.S : 0);
+        const uint8_t* Rc = a.leaf_codes + (cR ? (size_t)idr * a.S : 0);
+        double Pl[16], Pr[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { Pl[u] = pk_uniform(Psh[q][u]); Pr[u] = pk_uniform(Psh[q][16 + u]); }   // scalar registers
-                for (int s0 = 0; s0 < a.S; s0 += a.T) {
-                    const int s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
-                    pm_lp col = pm_lp_init();
-                    pk_rowregs A;
-                    if (cL && cR) {
-                        pk_twist_row_cc(s0, s1, Lc, Rc, tab[q][0], tab[q][1], pi, col);
-                    } else if (cL) {
-                        const char* bl = pk_uniform_ptr(Lc); const char* br = pk_uniform_ptr(Rp);
-                        pk_rows_load<true, false>(A, bl, br, s0 + lane, s1);
-                        pk_rows_run<true, false>(s0, s1, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
-                    } else if (cR) {
-                        const char* bl = pk_uniform_ptr(Lp); const char* br = pk_uniform_ptr(Rc);
-                        pk_rows_load<false, true>(A, bl, br, s0 + lane, s1);
-                        pk_rows_run<false, true>(s0, s1, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
-                    } else {
-                        const char* bl = pk_uniform_ptr(Lp); const char* br = pk_uniform_ptr(Rp);
-                        pk_rows_load<false, false>(A, bl, br, s0 + lane, s1);
-                        pk_rows_run<false, false>(s0, s1, bl, br, A, Pl, Pr, tab[q][0], tab[q][1], nullptr, pi, col);
-                    }
-                    const double t = pk_wave_tree_sum(pm_lp_finish(col));
-                    tot = s0 ? tot + t : t;
-                }
-            }
-            if (lane == 0) {
-                const int m = row - (row / M) * M;
-                const int c1 = co[r1], c2 = co[r2], c12 = c1 + c2;
-                double jp = tot + (-a.ldf[c12 < a.ldf_n ? c12 : a.ldf_n]);
-                jp = jp - (rl[r1] + (-a.ldf[c1 < a.ldf_n ? c1 : a.ldf_n]));
-                jp = jp - (rl[r2] + (-a.ldf[c2 < a.ldf_n ? c2 : a.ldf_n]));
-                ta.pot[(size_t)k * ta.J + (size_t)(t0 + r2 - r1 - 1) * M + m] = jp;
-            }
+        for (int u = 0; u < 16; ++u) { Pl[u] = P[u]; Pr[u] = P[16 + u]; }
+        if (cL || cR) {
+            if (lane < 32) pk_build_leaf_table(P, tab[0], lane);
+            else pk_build_leaf_table(P + 16, tab[1], lane - 32);
+            pk_wave_lds_fence();
         }
-        __syncthreads();
+        for (int s0 = 0; s0 < a.S; s0 += a.T) {
+            const int s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
+            pm_lp col = pm_lp_init();
+            pk_rowregs A;
+            if (cL && cR) {
+                pk_twist_row_cc(s0, s1, Lc, Rc, tab[0], tab[1], pi, col);
+            } else if (cL) {
+                const char* bl = pk_uniform_ptr(Lc); const char* br = pk_uniform_ptr(Rp);
+                pk_rows_load<true, false>(A, bl, br, s0 + lane, s1);
+                pk_rows_run<true, false>(s0, s1, bl, br, A, Pl, Pr, tab[0], tab[1], nullptr, pi, col);
+            } else if (cR) {
+                const char* bl = pk_uniform_ptr(Lp); const char* br = pk_uniform_ptr(Rc);
+                pk_rows_load<false, true>(A, bl, br, s0 + lane, s1);
+                pk_rows_run<false, true>(s0, s1, bl, br, A, Pl, Pr, tab[0], tab[1], nullptr, pi, col);
+            } else {
+                const char* bl = pk_uniform_ptr(Lp); const char* br = pk_uniform_ptr(Rp);
+                pk_rows_load<false, false>(A, bl, br, s0 + lane, s1);
+                pk_rows_run<false, false>(s0, s1, bl, br, A, Pl, Pr, tab[0], tab[1], nullptr, pi, col);
+            }
+            const double t = pk_wave_tree_sum(pm_lp_finish(col));
+            tot = s0 ? tot + t : t;
+        }
+    }
+    if (lane == 0) {
+        const int32_t* co = ta.cnt_ad + (size_t)kg * a.N;
+        const double* rl = ta.rootll_ad + (size_t)kg * a.N;
+        const int c1 = co[r1], c2 = co[r2], c12 = c1 + c2;
+        double jp = tot + (-a.ldf[c12 < a.ldf_n ? c12 : a.ldf_n]);
+        jp = jp - (rl[r1] + (-a.ldf[c1 < a.ldf_n ? c1 : a.ldf_n]));
+        jp = jp - (rl[r2] + (-a.ldf[c2 < a.ldf_n ? c2 : a.ldf_n]));
+        ta.pot[(size_t)k * J + j] = jp;
     }
 }
 

@@ -177,9 +177,11 @@ inline pg_parents_info pg_build_parents(int N, int R, int K, const int32_t* chil
     cur.resize((tail_flagged ? 2 : 1) * (nn + 64));
     int32_t* front = cur.data();
     memcpy(front, L.par_off, nn * 4);
-    if (tail_flagged) {                                     // (the cursors from the back: the row behind the front cursors)
-        int32_t* back = front + nn + 64;
+    memset(front + nn, 0, 64 * 4);                          // the 64 dummy cursors start from 0 at every call (their values are masked
+    if (tail_flagged) {                                     //  out of the result; left alone they would count up from call to call)
+        int32_t* back = front + nn + 64;                    // (the cursors from the back: the row behind the front cursors)
         for (size_t x = 0; x < nn; ++x) back[x] = L.par_off[x + 1] - 1;
+        memset(back + nn, 0, 64 * 4);
     }
     const int32_t free_bit = rows_form ? PG_FREE_PARENT : 0;
     const int32_t tail = (int32_t)(2 * nn) - 1;

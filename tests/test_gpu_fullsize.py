@@ -226,6 +226,30 @@ def test_batched_sweeps_in_every_form(G, Kg):
     ctx.close()
 
 
+def test_one_launch_batches_of_different_G_on_one_context():
+    """The one-launch sweep's arrival counters are per group and monotone: a batch with another number of groups that plans
+    the same workgroups per group must not find stale counters in the groups the previous batch did not use (K = 6144: G = 3
+    then G = 4 then G = 3 again; every batch bit for bit its oracle sweeps, the batched log Z fetch included)."""
+    g = load_dataset('primate_data')['genome']
+    N = g.shape[0]
+    Q = O.get_Q(O.init_y_q())
+    lam = np.full(N - 1, 10.0)
+    K = 6144
+    ctx = ctx_for(g, K, Q)
+    for G in (3, 4, 3, 6):
+        Kg = K // G
+        seeds = [11 * G + i for i in range(G)]
+        ctx.sweep_batch_async(seeds, flags=_ffi.FLAGS_DEFAULT | _ffi.ONE_LAUNCH)
+        logz = ctx.sweep_fetch_logz(G)
+        out = ctx.sweep_fetch()
+        assert out['stats']['n_launches'] == 1
+        refs = [CO.sweep(g, Q, PI, lam, lam, Kg, s) for s in seeds]
+        assert same_bits(out['log_weights'], np.concatenate([r['log_weights'] for r in refs], axis=1)), "G=%d" % G
+        np.testing.assert_array_equal(out['ancestors'], np.concatenate([r['ancestors'] for r in refs], axis=1))
+        assert list(logz) == [r['logZ'] for r in refs]
+    ctx.close()
+
+
 def test_one_launch_is_deterministic_with_contexts_in_flight():
     """Three contexts in flight, each a one-launch sweep of 256 resident workgroups: every repetition of a seed gives the same
     bits (a stale read across workgroups or a lost arrival would show here)."""
