@@ -1355,11 +1355,11 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
         const dim3 mgrid((unsigned)mitems);
         if (timek && !twist) {  // events stamped with the kernel's own begin/end (what rocprofv3 --kernel-trace reports)
             if (nostore) hipExtLaunchKernelGGL(pk_rank_merge_nostore, mgrid, dim3(64), 0, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
-            else hipExtLaunchKernelGGL(pk_rank_merge, mgrid, dim3(PK_COLS), (size_t)(c->site_tile < S ? c->site_tile : S) * 8, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
+            else hipExtLaunchKernelGGL(pk_rank_merge, mgrid, dim3(PK_COLS), (size_t)(c->site_tile < S ? c->site_tile : S) * 8 + 16 + PK_STORE_STAGE_BYTES, c->stream, c->kev[2 * r], c->kev[2 * r + 1], 0, b);
         } else if (nostore) {
             hipLaunchKernelGGL(pk_rank_merge_nostore, mgrid, dim3(64), 0, c->stream, b);
         } else {
-            hipLaunchKernelGGL(pk_rank_merge, mgrid, dim3(PK_COLS), (size_t)(c->site_tile < S ? c->site_tile : S) * 8, c->stream, b);
+            hipLaunchKernelGGL(pk_rank_merge, mgrid, dim3(PK_COLS), (size_t)(c->site_tile < S ? c->site_tile : S) * 8 + 16 + PK_STORE_STAGE_BYTES, c->stream, b);
         }
         if (c->ntiles > 1) {    // rows longer than one tile: tile values left to right, then the particle's weight terms
             CHK(launch_check(c, "pk_rank_merge"));

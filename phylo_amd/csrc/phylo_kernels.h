@@ -64,6 +64,7 @@ __device__ __forceinline__ double pk_wave_tree_sum(double v) {
 // (uncounted waits, no software pipelining).  Loads go through an explicit global-address-space pointer.
 typedef double pk_d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const pk_d2 pk_gd2c;
+typedef __attribute__((address_space(1))) pk_d2 pk_gd2;
 __device__ __forceinline__ pk_d2 pk_gload2(const double* p) { return *(pk_gd2c*)p; }
 
 __device__ __forceinline__ void pk_load4(const double* __restrict__ p, double* v) {
@@ -1234,22 +1235,6 @@ __global__ __launch_bounds__(PK_COLS) void pk_rank_scan_book(const pk_rank_args 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// The Felsenstein merge of one rank event in the form that STORES the node: one workgroup of 256 threads per (local particle,
-// site tile); grid = Kloc x ntiles.
-//   k2: the new node's partial likelihoods, out[s,:] = (L[s,:] P_l) * (R[s,:] P_r)      (vcsmc.py:185-187)
-//   k3: sum_s log(pi . out[s,:]) in the canonical order                                  (vcsmc.py:240-242)
-//   k8: log_likelihood_r and log w_r                                                     (vcsmc.py:376-392)
-// Phase 1, all four waves (what bounds this kernel is the store stream, so the rows are spread over as many waves as the
-// old 256-column form had): a lane PAIR owns a site.  Lane parity h loads the 16 bytes holding states 2h, 2h+1 of each child
-// (a wave reads 1 KiB contiguous per instruction from the [K x S x 4] tensor), completes the rows with DPP quad_perm moves,
-// produces output states 2h, 2h+1 and stores its 16 bytes (non-temporal: only the few particles that survive the next
-// resampling ever read the node again); the site's likelihood pi . out goes to LDS.  128 sites per step.
-// Phase 2, wave 0: the tile's 64 column products (contract v5: lane = column, sites in increasing order, read back from LDS),
-// one log per lane, the tree, the epilogue.  Arithmetic per output state is the same fma chain as pk_merge_site: results are
-// bit-identical to the row-per-lane form.
-//   algorithmic traffic: 2 x 32 B read + 32 B written per (particle, site) = 96 B / unit.
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double pk_dpp_even(double v) {   // the value held by the even lane of my pair
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_mov_dpp(lo, 0xA0, 0xF, 0xF, true);       // quad_perm [0,0,2,2]
@@ -1286,68 +1271,6 @@ __device__ __forceinline__ void pk_build_leaf_table(const double* __restrict__ P
     }
 }
 
-// sites [s0, s1) of one tile by one workgroup; thread = 2 p + h, pair p owns sites s0 + p + 128 q
-template <bool CL, bool CR, bool STORE>
-__device__ __forceinline__ void pk_merge_body(const pk_rank_args& a, int s0, int s1, const double* Lp, const double* Rp,
-                                              const uint8_t* Lc, const uint8_t* Rc, double* out,
-                                              const double (&Plc)[4][2], const double (&Prc)[4][2],
-                                              const double (*tabL)[4], const double (*tabR)[4], double* likbuf, int p, int h) {
-    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
-    // software pipeline: the next step's rows (or codes) are fetched before this step is computed
-    pk_d2 nl = {0, 0}, nr = {0, 0};
-    int ncl = 0, ncr = 0;
-    if (s0 + p < s1) {
-        if (CL) ncl = Lc[s0 + p]; else nl = pk_gload2(Lp + (size_t)(s0 + p) * 4);
-        if (CR) ncr = Rc[s0 + p]; else nr = pk_gload2(Rp + (size_t)(s0 + p) * 4);
-    }
-    const int nq = (s1 - s0 + 127) >> 7;
-    for (int q = 0; q < nq; ++q) {
-        const int s = s0 + p + 128 * q;
-        const bool valid = s < s1;
-        const pk_d2 l2 = nl, r2 = nr;
-        const int cl = ncl, cr = ncr;
-        if (s + 128 < s1) {
-            if (CL) ncl = Lc[s + 128]; else nl = pk_gload2(Lp + (size_t)(s + 128) * 4);
-            if (CR) ncr = Rc[s + 128]; else nr = pk_gload2(Rp + (size_t)(s + 128) * 4);
-        }
-        double lp[2], rp[2];
-        if (CL) {
-            const pk_d2 v = *reinterpret_cast<const pk_d2*>(&tabL[cl][2 * h]);      // one ds_read_b128
-            lp[0] = v.x; lp[1] = v.y;
-        } else {
-            const double L[4] = {pk_dpp_even(l2.x), pk_dpp_even(l2.y), pk_dpp_odd(l2.x), pk_dpp_odd(l2.y)};
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                double v = L[0] * Plc[0][c];
-                v = pm_fma(L[1], Plc[1][c], v);
-                v = pm_fma(L[2], Plc[2][c], v);
-                lp[c] = pm_fma(L[3], Plc[3][c], v);
-            }
-        }
-        if (CR) {
-            const pk_d2 v = *reinterpret_cast<const pk_d2*>(&tabR[cr][2 * h]);
-            rp[0] = v.x; rp[1] = v.y;
-        } else {
-            const double R[4] = {pk_dpp_even(r2.x), pk_dpp_even(r2.y), pk_dpp_odd(r2.x), pk_dpp_odd(r2.y)};
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                double v = R[0] * Prc[0][c];
-                v = pm_fma(R[1], Prc[1][c], v);
-                v = pm_fma(R[2], Prc[2][c], v);
-                rp[c] = pm_fma(R[3], Prc[3][c], v);
-            }
-        }
-        const double o[2] = {lp[0] * rp[0], lp[1] * rp[1]};
-        if (STORE && valid) {
-            const pk_d2 ov = {o[0], o[1]};
-            __builtin_nontemporal_store(ov, reinterpret_cast<pk_d2*>(out + (size_t)s * 4));
-        }
-        const double f[4] = {pk_dpp_even(o[0]), pk_dpp_even(o[1]), pk_dpp_odd(o[0]), pk_dpp_odd(o[1])};
-        const double lik = pk_site_lik(pi, f);
-        if (valid && h == 0) likbuf[s - s0] = lik;
-    }
-}
-
 // log_likelihood_r and log w_r of the particle from the new node's log-likelihood and the bookkeeping terms (k8)
 __device__ __forceinline__ void pk_merge_epilogue(const pk_rank_args& a, int k, int kg, double tot) {
     const double* ax = a.aux + (size_t)k * PK_AUX;
@@ -1368,61 +1291,6 @@ __global__ __launch_bounds__(256) void pk_tile_epilogue(const pk_rank_args a) {
     double tot = tv[0];
     for (int t = 1; t < a.ntiles; ++t) tot = tot + tv[t];
     pk_merge_epilogue(a, k, a.k0 + k, tot);
-}
-
-#define PK_MAX_SITE_TILE 4096            // the storing merge keeps a tile's site likelihoods in LDS (8 bytes each)
-__global__ __launch_bounds__(PK_COLS, 5) void pk_rank_merge(const pk_rank_args a) {
-    extern __shared__ __attribute__((aligned(16))) double pk_likbuf[];        // [T] site likelihoods of this tile
-    __shared__ __attribute__((aligned(16))) double tabL[5][4], tabR[5][4];
-    const int item = blockIdx.x, k = a.ntiles == 1 ? item : item / a.ntiles, tau = item - k * a.ntiles;
-    const int kg = a.k0 + k, tid = threadIdx.x, p = tid >> 1, h = tid & 1;
-    const int s0 = tau * a.T, s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
-    const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
-    const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // workgroup-uniform
-    const double* Lp = pk_node_ptr(a, cl) + 2 * h;
-    const double* Rp = pk_node_ptr(a, cr) + 2 * h;
-    const uint8_t* Lc = a.leaf_codes + (codedL ? (size_t)cl * a.S : 0);
-    const uint8_t* Rc = a.leaf_codes + (codedR ? (size_t)cr * a.S : 0);
-    double* out = a.pool + ((size_t)a.r * a.Kloc + k) * (size_t)a.S * 4 + 2 * h;
-    const double* P = a.Pmat + (size_t)k * 32 + 2 * h;
-    double Plc[4][2], Prc[4][2];                    // my two columns (states 2h, 2h+1) of P_l and P_r
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const pk_d2 x = *reinterpret_cast<const pk_d2*>(P + i * 4);
-        const pk_d2 y = *reinterpret_cast<const pk_d2*>(P + 16 + i * 4);
-        Plc[i][0] = x.x; Plc[i][1] = x.y; Prc[i][0] = y.x; Prc[i][1] = y.y;
-    }
-    if (codedL || codedR) {
-        const double* Pu = a.Pmat + (size_t)k * 32;
-        if (tid < 32) pk_build_leaf_table(Pu, tabL, tid);
-        else if (tid < 64) pk_build_leaf_table(Pu + 16, tabR, tid - 32);
-        __syncthreads();
-    }
-#define PK_MERGE_DISPATCH(ST)                                                                                           \
-    if (codedL) {                                                                                                       \
-        if (codedR) pk_merge_body<true, true, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, pk_likbuf, p, h);   \
-        else pk_merge_body<true, false, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, pk_likbuf, p, h);         \
-    } else {                                                                                                            \
-        if (codedR) pk_merge_body<false, true, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, pk_likbuf, p, h);  \
-        else pk_merge_body<false, false, ST>(a, s0, s1, Lp, Rp, Lc, Rc, out, Plc, Prc, tabL, tabR, pk_likbuf, p, h);        \
-    }
-    if (a.lazy || a.no_store) { PK_MERGE_DISPATCH(false) } else { PK_MERGE_DISPATCH(true) }
-#undef PK_MERGE_DISPATCH
-    __syncthreads();
-    if (tid >= 64) return;
-    // phase 2: lane = column of the tile; the column's sites in increasing order, two per renormalisation
-    pm_lp col = pm_lp_init();
-    const int len = s1 - s0;
-    for (int j = tid; j < len; j += 128) {
-        const double xa = pk_likbuf[j];
-        if (j + 64 < len) pm_lp_mul2(col, xa, pk_likbuf[j + 64]);
-        else pm_lp_mul(col, xa);
-    }
-    const double tot = pk_wave_tree_sum(pm_lp_finish(col));
-    if (tid == 0) {
-        if (a.ntiles == 1) pk_merge_epilogue(a, k, kg, tot);
-        else a.tilev[(size_t)k * a.ntiles + tau] = tot;
-    }
 }
 
 // multi-GPU: after the all-gather of node log-likelihoods, complete the root tables of the other ranks'
@@ -1584,6 +1452,40 @@ __device__ __forceinline__ void pk_rows_load(pk_rowregs& x, const char* bl, cons
     else { x.r0 = *(pk_gu4c*)(br + sc * 32u); x.r1 = *(pk_gu4c*)(br + sc * 32u + 16u); }
 }
 __device__ __forceinline__ double pk_u2d(unsigned int lo, unsigned int hi) { return __hiloint2double((int)hi, (int)lo); }
+// the new node's row (L P_l) o (R P_r) of the loaded rows / codes
+template <bool CL, bool CR>
+__device__ __forceinline__ void pk_rows_out(const pk_rowregs& x, const double (&Pl)[16], const double (&Pr)[16], const double (*tabL)[4],
+                                            const double (*tabR)[4], double (&o)[4]) {
+    double lpv[4], rpv[4];
+    if constexpr (CL) {
+        const pk_d2 a = *reinterpret_cast<const pk_d2*>(&tabL[x.cl][0]), b = *reinterpret_cast<const pk_d2*>(&tabL[x.cl][2]);
+        lpv[0] = a.x; lpv[1] = a.y; lpv[2] = b.x; lpv[3] = b.y;
+    } else {
+        const double Lv[4] = {pk_u2d(x.l0.x, x.l0.y), pk_u2d(x.l0.z, x.l0.w), pk_u2d(x.l1.x, x.l1.y), pk_u2d(x.l1.z, x.l1.w)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double v = Lv[0] * Pl[j];
+            v = pm_fma(Lv[1], Pl[4 + j], v);
+            v = pm_fma(Lv[2], Pl[8 + j], v);
+            lpv[j] = pm_fma(Lv[3], Pl[12 + j], v);
+        }
+    }
+    if constexpr (CR) {
+        const pk_d2 a = *reinterpret_cast<const pk_d2*>(&tabR[x.cr][0]), b = *reinterpret_cast<const pk_d2*>(&tabR[x.cr][2]);
+        rpv[0] = a.x; rpv[1] = a.y; rpv[2] = b.x; rpv[3] = b.y;
+    } else {
+        const double Rv[4] = {pk_u2d(x.r0.x, x.r0.y), pk_u2d(x.r0.z, x.r0.w), pk_u2d(x.r1.x, x.r1.y), pk_u2d(x.r1.z, x.r1.w)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double v = Rv[0] * Pr[j];
+            v = pm_fma(Rv[1], Pr[4 + j], v);
+            v = pm_fma(Rv[2], Pr[8 + j], v);
+            rpv[j] = pm_fma(Rv[3], Pr[12 + j], v);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = lpv[j] * rpv[j];
+}
 // the site likelihood pi . ((L P_l) o (R P_r)) of the loaded rows / codes
 template <bool CL, bool CR>
 __device__ __forceinline__ double pk_rows_lik(const pk_rowregs& x, const double (&Pl)[16], const double (&Pr)[16], const double (*tabL)[4],
@@ -1591,35 +1493,8 @@ __device__ __forceinline__ double pk_rows_lik(const pk_rowregs& x, const double 
     if constexpr (CL && CR) {
         return lik25[x.cl * 5 + x.cr];
     } else {
-        double lpv[4], rpv[4], o[4];
-        if constexpr (CL) {
-            const pk_d2 a = *reinterpret_cast<const pk_d2*>(&tabL[x.cl][0]), b = *reinterpret_cast<const pk_d2*>(&tabL[x.cl][2]);
-            lpv[0] = a.x; lpv[1] = a.y; lpv[2] = b.x; lpv[3] = b.y;
-        } else {
-            const double Lv[4] = {pk_u2d(x.l0.x, x.l0.y), pk_u2d(x.l0.z, x.l0.w), pk_u2d(x.l1.x, x.l1.y), pk_u2d(x.l1.z, x.l1.w)};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double v = Lv[0] * Pl[j];
-                v = pm_fma(Lv[1], Pl[4 + j], v);
-                v = pm_fma(Lv[2], Pl[8 + j], v);
-                lpv[j] = pm_fma(Lv[3], Pl[12 + j], v);
-            }
-        }
-        if constexpr (CR) {
-            const pk_d2 a = *reinterpret_cast<const pk_d2*>(&tabR[x.cr][0]), b = *reinterpret_cast<const pk_d2*>(&tabR[x.cr][2]);
-            rpv[0] = a.x; rpv[1] = a.y; rpv[2] = b.x; rpv[3] = b.y;
-        } else {
-            const double Rv[4] = {pk_u2d(x.r0.x, x.r0.y), pk_u2d(x.r0.z, x.r0.w), pk_u2d(x.r1.x, x.r1.y), pk_u2d(x.r1.z, x.r1.w)};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double v = Rv[0] * Pr[j];
-                v = pm_fma(Rv[1], Pr[4 + j], v);
-                v = pm_fma(Rv[2], Pr[8 + j], v);
-                rpv[j] = pm_fma(Rv[3], Pr[12 + j], v);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = lpv[j] * rpv[j];
+        double o[4];
+        pk_rows_out<CL, CR>(x, Pl, Pr, tabL, tabR, o);
         return pk_site_lik(pi, o);
     }
 }
@@ -1763,6 +1638,117 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
             ka->ll_r[kg] = ll;
             ka->logw_r[kg] = lw;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The Felsenstein merge of one rank event in the form that STORES the node: one workgroup of 256 threads per (local particle,
+// site tile); grid = Kloc x ntiles.  Used where every node must be in memory (PHYLO_EAGER_NODES, the twisted proposal, kept
+// graphs of long rows, small sharded nodes).
+//   k2: the new node's partial likelihoods, out[s,:] = (L[s,:] P_l) * (R[s,:] P_r)      (vcsmc.py:185-187)
+//   k3: sum_s log(pi . out[s,:]) in the canonical order                                  (vcsmc.py:240-242)
+//   k8: log_likelihood_r and log w_r                                                     (vcsmc.py:376-392)
+// Phase 1, all four waves (what should bound this kernel is the store stream): row-per-lane like pk_rank_merge_nostore -- wave w
+// takes the 64-site steps w, w + 4, ... of the tile, lane = site, both matrices in scalar registers -- and the 32-byte output
+// rows of a step go through 2 KiB of the wave's LDS so that every store instruction writes 1 KiB CONTIGUOUS, 16 bytes per lane
+// (non-temporal: only the few particles that survive the next resampling ever read the node again); the site's likelihood
+// pi . out goes to LDS.  (Until round 3 a lane PAIR owned a site and the rows were completed with DPP moves: 114 VALU
+// instructions per site, a third of them 4-cycle DPP moves, bound the launch at 0.45-0.54 of the HBM peak.  Row-per-lane stores
+// of 2 x 16 bytes at a 32-byte stride write half lines and were slower still.)
+// Phase 2, wave 0: the tile's 64 column products (contract v5: lane = column, sites in increasing order, read back from LDS),
+// one log per lane, the tree, the epilogue.  Same fma chains as everywhere: bit-identical to the other forms.
+//   algorithmic traffic: 2 x 32 B read + 32 B written per (particle, site) = 96 B / unit.
+// ------------------------------------------------------------------------------------------------
+#define PK_MAX_SITE_TILE 4096            // the storing merge keeps a tile's site likelihoods in LDS (8 bytes each)
+#define PK_STORE_STAGE_BYTES 8192        // + 2 KiB of output staging per wave
+template <bool CL, bool CR, bool STORE>
+__device__ __forceinline__ void pk_store_tile(int s0, int s1, int wv, int lane, const double* Lp, const double* Rp, const uint8_t* Lc,
+                                              const uint8_t* Rc, double* out, const double (&Pl)[16], const double (&Pr)[16],
+                                              const double (*tabL)[4], const double (*tabR)[4], const double (&pi)[4], double* likbuf,
+                                              double* stage /*this wave's [64][4]*/) {
+    const char* bl = pk_uniform_ptr(CL ? (const void*)Lc : (const void*)Lp);
+    const char* br = pk_uniform_ptr(CR ? (const void*)Rc : (const void*)Rp);
+    char* ob = const_cast<char*>(pk_uniform_ptr(out));
+    pk_rowregs A, B;
+    int u = s0 + 64 * wv;                                   // wave-uniform: first site of this wave's step
+    if (u >= s1) return;
+    pk_rows_load<CL, CR>(A, bl, br, u + lane, s1);
+    #pragma unroll 1
+    for (; u < s1; u += 256) {
+        pk_rows_load<CL, CR>(B, bl, br, u + 256 + lane, s1);        // the next step's rows travel while this one is computed
+        double o[4];
+        pk_rows_out<CL, CR>(A, Pl, Pr, tabL, tabR, o);
+        const int s = u + lane;
+        if (s < s1) likbuf[s - s0] = pk_site_lik(pi, o);
+        if constexpr (STORE) {
+            // transpose through LDS: lane l wrote its row (32 bytes at 32 l); piece i of the step's 2 KiB is read back 16 bytes per
+            // lane (offset 1024 i + 16 l) and stored 1 KiB contiguous per instruction
+            pk_d2* st = reinterpret_cast<pk_d2*>(stage);
+            st[2 * lane] = pk_d2{o[0], o[1]};
+            st[2 * lane + 1] = pk_d2{o[2], o[3]};
+            pk_wave_lds_fence();
+            const int nbytes = (s1 - u < 64 ? s1 - u : 64) * 32;             // valid bytes of this step
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int off = 1024 * i + 16 * lane;
+                const pk_d2 v = st[64 * i + lane];
+                if (off < nbytes) __builtin_nontemporal_store(v, (pk_gd2*)(ob + (size_t)u * 32 + off));   // global_store, not flat
+            }
+            pk_wave_lds_fence();
+        }
+        A = B;
+    }
+}
+
+__global__ __launch_bounds__(PK_COLS) __attribute__((amdgpu_waves_per_eu(5, 8))) void pk_rank_merge(const pk_rank_args a) {
+    extern __shared__ __attribute__((aligned(16))) double pk_lds_dyn[];     // [tile sites] site likelihoods, then 4 x [64][4] staging
+    __shared__ __attribute__((aligned(16))) double tabL[5][4], tabR[5][4];
+    const int item = blockIdx.x, k = a.ntiles == 1 ? item : item / a.ntiles, tau = item - k * a.ntiles;
+    const int kg = a.k0 + k, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int s0 = tau * a.T, s1 = s0 + a.T < a.S ? s0 + a.T : a.S, len = s1 - s0;
+    double* likbuf = pk_lds_dyn;
+    double* stage = pk_lds_dyn + ((len + 1) & ~1) + (size_t)wv * 256;
+    const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
+    const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // workgroup-uniform
+    const double* Lp = pk_node_ptr(a, cl);
+    const double* Rp = pk_node_ptr(a, cr);
+    const uint8_t* Lc = a.leaf_codes + (codedL ? (size_t)cl * a.S : 0);
+    const uint8_t* Rc = a.leaf_codes + (codedR ? (size_t)cr * a.S : 0);
+    double* out = a.pool + ((size_t)a.r * a.Kloc + k) * (size_t)a.S * 4;
+    const double* Pu = a.Pmat + (size_t)k * 32;
+    double Pl[16], Pr[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { Pl[u] = Pu[u]; Pr[u] = Pu[16 + u]; }   // uniform address: scalar loads
+    const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+    if (codedL || codedR) {
+        if (tid < 32) pk_build_leaf_table(Pu, tabL, tid);
+        else if (tid < 64) pk_build_leaf_table(Pu + 16, tabR, tid - 32);
+        __syncthreads();
+    }
+#define PK_MERGE_DISPATCH(ST)                                                                                                          \
+    if (codedL) {                                                                                                                      \
+        if (codedR) pk_store_tile<true, true, ST>(s0, s1, wv, lane, Lp, Rp, Lc, Rc, out, Pl, Pr, tabL, tabR, pi, likbuf, stage);        \
+        else pk_store_tile<true, false, ST>(s0, s1, wv, lane, Lp, Rp, Lc, Rc, out, Pl, Pr, tabL, tabR, pi, likbuf, stage);              \
+    } else {                                                                                                                           \
+        if (codedR) pk_store_tile<false, true, ST>(s0, s1, wv, lane, Lp, Rp, Lc, Rc, out, Pl, Pr, tabL, tabR, pi, likbuf, stage);       \
+        else pk_store_tile<false, false, ST>(s0, s1, wv, lane, Lp, Rp, Lc, Rc, out, Pl, Pr, tabL, tabR, pi, likbuf, stage);             \
+    }
+    if (a.lazy || a.no_store) { PK_MERGE_DISPATCH(false) } else { PK_MERGE_DISPATCH(true) }
+#undef PK_MERGE_DISPATCH
+    __syncthreads();
+    if (tid >= 64) return;
+    // phase 2: lane = column of the tile; the column's sites in increasing order, two per renormalisation
+    pm_lp col = pm_lp_init();
+    for (int j = tid; j < len; j += 128) {
+        const double xa = likbuf[j];
+        if (j + 64 < len) pm_lp_mul2(col, xa, likbuf[j + 64]);
+        else pm_lp_mul(col, xa);
+    }
+    const double tot = pk_wave_tree_sum(pm_lp_finish(col));
+    if (tid == 0) {
+        if (a.ntiles == 1) pk_merge_epilogue(a, k, kg, tot);
+        else a.tilev[(size_t)k * a.ntiles + tau] = tot;
     }
 }
 
