@@ -47,7 +47,8 @@ struct sweep_run {                       // a sweep being issued rank event by r
 struct env_switches {
     bool eager_nodes = false, rehearse_sharded = false, replicated_book = false, fuse_scan = false,
          book_one_per_wave = false, merge_pair_form = false, no_leaf_codes = false, one_launch = false,
-         persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, no_spin_wait = false;
+         persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, no_spin_wait = false,
+         no_p2p = false;
     int persist_wgs = 0;                 // PHYLO_PERSIST_WGS: resident workgroups of the one-launch sweep (0 = default)
     int persist_nt = 256;                // PHYLO_PERSIST_NT: threads per workgroup of the one-launch sweep (256 or 512)
     void read() {
@@ -64,6 +65,7 @@ struct env_switches {
         grad_one_stream = getenv("PHYLO_GRAD_ONE_STREAM") != nullptr;
         grad_two_streams = getenv("PHYLO_GRAD_TWO_STREAMS") != nullptr;
         no_spin_wait = getenv("PHYLO_NO_SPIN_WAIT") != nullptr;
+        { const char* e = getenv("PHYLO_P2P"); no_p2p = e && atoi(e) == 0; }
         const char* w = getenv("PHYLO_PERSIST_WGS");
         persist_wgs = w ? atoi(w) : 0;
         const char* t = getenv("PHYLO_PERSIST_NT");
@@ -122,6 +124,12 @@ struct phylo_ctx {
     int32_t* d_child = nullptr;          // [(N-1)][Kloc][2]: children of every node (kept for lazy materialisation)
     unsigned int* d_mark = nullptr;      // [(N-1)][K]: node is in the pool
     double* d_sync = nullptr;  // [world] dummy payload of the barrier collective used by lazy nodes when sharded
+    // device-side exchange between ranks (pk_p2p_exchange): the all-gathered arrays live in ONE fine-grained slab that the peers map
+    bool p2p = false;
+    char* d_xslab = nullptr;             // logw | ll | nodell | chosen | sync | flags[2][world]
+    size_t xslab_bytes = 0, x_flag_off[2] = {0, 0};
+    char** d_xslab_ptrs = nullptr;       // [world] every rank's slab as mapped here
+    unsigned long long x_epoch[2] = {0, 0};   // exchanges / barriers issued so far (the same on every rank)
     bool last_lazy = false;
     int32_t* d_merges = nullptr;         // [(N-1)][Kloc][2]
     int64_t* d_anc = nullptr;            // [(N-2)][Kloc]
@@ -258,6 +266,16 @@ void free_sweep_state(phylo_ctx* c) {
     // the reverse pass's side streams may still read what is freed below
     if (c->gstream) (void)hipStreamSynchronize(c->gstream);
     if (c->bgstream) (void)hipStreamSynchronize(c->bgstream);
+    if (c->d_xslab) {                                       // the exchanged arrays are carved from the slab
+        (void)hipFree(c->d_xslab);
+        c->d_xslab = nullptr;
+        c->d_logw = c->d_ll = c->d_nodell = c->d_sync = nullptr;
+        c->d_chosen = nullptr;
+    }
+    if (c->d_xslab_ptrs) (void)hipFree((void*)c->d_xslab_ptrs);
+    c->d_xslab_ptrs = nullptr;
+    c->xslab_bytes = 0;
+    c->x_epoch[0] = c->x_epoch[1] = 0;
     if (c->d_twbuf) (void)hipFree(c->d_twbuf);
     c->d_twbuf = nullptr;
     c->twbuf_cap = 0;
@@ -331,12 +349,39 @@ int alloc_sweep_state(phylo_ctx* c) {
     c->state_ready = false;
     const size_t R = (size_t)c->N - 1, K = c->K, Kl = c->Kloc, N = c->N, S = c->S;
     CHK(dalloc(c, &c->d_pool, R * Kl * S * 4));
+    // Sharded: the arrays that cross ranks at every rank event live in one slab of FINE-GRAINED device memory (peers write into
+    // it over xGMI and this rank reads it in later kernels: no stale line may survive in this device's L2) that every peer maps.
+    c->p2p = c->comm.transport != 0 && c->world > 1 && !c->env.no_p2p && R >= 2;
+    if (c->p2p) {
+        const size_t al = 32;                               // doubles: 256-byte alignment of every array
+        auto up = [&](size_t n) { return (n + al - 1) / al * al; };
+        const size_t n_logw = up(R * K), n_nod = up(N + R * K), n_ch = up(K), n_sy = up((size_t)c->world), n_fl = up((size_t)c->world);
+        const size_t total = 2 * n_logw + n_nod + n_ch + n_sy + 2 * n_fl;
+        void* slab = nullptr;
+        if (hipExtMallocWithFlags(&slab, total * 8, hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(c, hipMalloc(&slab, total * 8));         // (coarse-grained: still correct on one device)
+        }
+        HIPCHK(c, hipMemset(slab, 0, total * 8));
+        c->d_xslab = (char*)slab;
+        c->xslab_bytes = total * 8;
+        double* base = (double*)slab;
+        c->d_logw = base; c->d_ll = base + n_logw; c->d_nodell = base + 2 * n_logw;
+        c->d_chosen = c->d_nodell + n_nod;
+        c->d_sync = c->d_chosen + n_ch;
+        c->x_flag_off[0] = (size_t)((char*)(c->d_sync + n_sy) - c->d_xslab);
+        c->x_flag_off[1] = c->x_flag_off[0] + n_fl * 8;
+        c->x_epoch[0] = c->x_epoch[1] = 0;
+    } else {
     CHK(dalloc(c, &c->d_nodell, N + R * K));
+    }
     CHK(dalloc(c, &c->d_bl, R * Kl));
     CHK(dalloc(c, &c->d_br, R * Kl));
     CHK(dalloc(c, &c->d_Pmat, R * Kl * 32));
-    CHK(dalloc(c, &c->d_logw, R * K));
-    CHK(dalloc(c, &c->d_ll, R * K));
+    if (!c->p2p) {
+        CHK(dalloc(c, &c->d_logw, R * K));
+        CHK(dalloc(c, &c->d_ll, R * K));
+    }
     CHK(dalloc(c, &c->d_aux, Kl * PK_AUX));
     if (c->ntiles > 1) CHK(dalloc(c, &c->d_tilev, Kl * (size_t)c->ntiles));
     CHK(dalloc(c, &c->d_lse, (R + 1) * PK_MAX_GROUPS));
@@ -349,7 +394,7 @@ int alloc_sweep_state(phylo_ctx* c) {
     }
     CHK(dalloc(c, &c->d_child, R * Kl * 2));
     CHK(dalloc(c, &c->d_mark, ((R * K + R + 3) & ~(size_t)3)));      // one mark per node
-    CHK(dalloc(c, &c->d_sync, (size_t)c->world));
+    if (!c->p2p) CHK(dalloc(c, &c->d_sync, (size_t)c->world));
     CHK(dalloc(c, &c->d_merges, R * Kl * 2));
     CHK(dalloc(c, &c->d_anc, (R > 0 ? R - 1 : 0) * Kl));
     CHK(dalloc(c, &c->d_cdf[0], K));
@@ -365,6 +410,12 @@ int alloc_sweep_state(phylo_ctx* c) {
     rc = phylo_comm_map_extra(c->comm, c->d_tables, &ptrs, c->stream, &c->err);
     if (rc != PHYLO_OK) return rc;
     HIPCHK(c, hipMemcpy((void*)c->d_tab_ptrs, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice));
+    if (c->p2p) {
+        CHK(dalloc(c, &c->d_xslab_ptrs, (size_t)c->world));
+        rc = phylo_comm_map_extra(c->comm, c->d_xslab, &ptrs, c->stream, &c->err);
+        if (rc != PHYLO_OK) return rc;
+        HIPCHK(c, hipMemcpy((void*)c->d_xslab_ptrs, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice));
+    }
     c->state_ready = true;
     return PHYLO_OK;
 }
@@ -895,7 +946,7 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
             CHK(dalloc(c, &c->d_roots_ad, (size_t)K * N));
             CHK(dalloc(c, &c->d_cnt_ad, (size_t)K * N));
             CHK(dalloc(c, &c->d_rootll_ad, (size_t)K * N));
-            CHK(dalloc(c, &c->d_chosen, (size_t)K));
+            if (!c->p2p) CHK(dalloc(c, &c->d_chosen, (size_t)K));
         }
         if (c->tw_capacity < (size_t)Kl * Jmax) {
             if (c->d_tw_b) { (void)hipFree(c->d_tw_b); (void)hipFree(c->d_tw_P); (void)hipFree(c->d_pot); }
@@ -1147,6 +1198,33 @@ static int sweep_persistent(phylo_ctx* c, uint64_t seed, uint32_t flags, const u
 
 int phylo_sweep_begin(phylo_ctx* c, uint64_t seed, uint32_t flags, int M) { return sweep_begin_impl(c, seed, flags, M, nullptr, 1); }
 
+// All-gather of this rank's segments of `n_arrays` arrays (`count` doubles per rank; arrays[i] = the array's base, rank p's segment
+// at + p * count), or with n_arrays == 0 a barrier across the ranks, on the context's stream.  With the exchange slab
+// (c->p2p) it is ONE launch of pk_p2p_exchange -- peers' slabs written over xGMI, flags, bounded wait: no collective call, no
+// second stream; otherwise the RCCL / host-mediated collective of phylo_comm.h.  purpose 0: the rank event's K-vectors; 1: barriers
+// and the twisted proposal's choices (own flags and epochs: every rank issues the same sequence of each).
+static int comm_exchange(phylo_ctx* c, double* const* arrays, int n_arrays, size_t count, int purpose) {
+    if (c->comm.transport == 0) return PHYLO_OK;
+    if (!c->p2p) {
+        if (n_arrays == 0) { double* rows[1] = {c->d_sync}; return phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err); }
+        return phylo_comm_allgather_inplace(c->comm, arrays, n_arrays, count, c->stream, &c->err);
+    }
+    if (n_arrays > 4) return fail(c, PHYLO_EINVAL, "comm_exchange: at most four arrays");
+    pk_p2p_args a{};
+    a.slabs = c->d_xslab_ptrs; a.world = c->world; a.me = c->rank;
+    a.n_seg = n_arrays; a.seg_count = (int)count;
+    for (int i = 0; i < n_arrays; ++i) {
+        const ptrdiff_t off = (const char*)arrays[i] - c->d_xslab;
+        if (off < 0 || (size_t)off + (size_t)c->world * count * 8 > c->xslab_bytes) return fail(c, PHYLO_EINVAL, "comm_exchange: array outside the exchange slab");
+        a.seg_off[i] = (size_t)off;
+    }
+    a.flag_off = c->x_flag_off[purpose];
+    a.epoch = ++c->x_epoch[purpose];
+    a.timeout_word = c->d_counter + 1;
+    hipLaunchKernelGGL(pk_p2p_exchange, dim3(1), dim3(1024), 0, c->stream, a);
+    return launch_check(c, "pk_p2p_exchange");
+}
+
 // Sharded lazy nodes, first half of a rank event: every rank marks the nodes adopted at this resampling (the search
 // of all K particles, no tables), the owner writes its marked nodes, and one tiny collective orders those writes before
 // every rank's merge.  A no-op otherwise.  phylo_sweep_step runs it when the caller has not (phylo_sweep_step_a).
@@ -1182,8 +1260,7 @@ static int sweep_step_a(phylo_ctx* c) {
         CHK(launch_check(c, "pk_materialize_adopted"));
         c->run.launches += 2;
     }
-    double* rows[1] = {c->d_sync};
-    CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
+    CHK(comm_exchange(c, nullptr, 0, 0, 1));               // barrier: the owners' writes before every rank's merge
     return PHYLO_OK;
 }
 
@@ -1281,7 +1358,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             CHK(launch_check(c, "pk_twist_choose"));
             if (c->comm.transport != 0) {
                 double* rows[1] = {c->d_chosen};
-                CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, (size_t)Kl, c->stream, &c->err));
+                CHK(comm_exchange(c, rows, 1, (size_t)Kl, 1));
             }
             if (!ta.own_tables) {
                 hipLaunchKernelGGL(pk_twist_tables, dim3(cdiv(K, 128)), dim3(128), 0, c->stream, ta);
@@ -1345,10 +1422,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             else hipLaunchKernelGGL(pk_materialize_adopted, dim3(S <= 4096 ? 1 : cdiv(S, PK_MAT_TILE), Kl), dim3(PK_COLS), 0, c->stream, b);
             CHK(launch_check(c, "pk_materialize_adopted"));
             ++launches;
-            if (c->comm.transport != 0) {      // peers read these nodes in place: order them before every rank's merge
-                double* rows[1] = {c->d_sync};
-                CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
-            }
+            if (c->comm.transport != 0) CHK(comm_exchange(c, nullptr, 0, 0, 1));   // peers read these nodes in place: order them before every rank's merge
         }
         const bool nostore = (b.lazy || b.no_store) && !c->env.merge_pair_form;   // row-per-lane form when nothing is stored
         const size_t mitems = (size_t)Kl * c->ntiles;                              // one wave per (particle, site tile)
@@ -1371,7 +1445,7 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
     }
     if (phase == 0 && c->comm.transport != 0) {
         double* rows[3] = {c->d_logw + (size_t)r * K, c->d_ll + (size_t)r * K, c->d_nodell + N + (size_t)r * K};
-        CHK(phylo_comm_allgather_inplace(c->comm, rows, 3, (size_t)Kl, c->stream, &c->err));
+        CHK(comm_exchange(c, rows, 3, (size_t)Kl, 0));
     }
     if (phase == 1) {
         c->run.launches += launches;
@@ -1438,7 +1512,12 @@ int phylo_sweep_step_group(phylo_ctx** ctxs, int n) {
         rows[3 * i + 1] = c->d_ll + r * K;
         rows[3 * i + 2] = c->d_nodell + c->N + r * K;
     }
-    {
+    if (ctxs[0]->p2p) {                                    // device-side exchange: every context has its own slab and flags
+        for (int i = 0; i < n; ++i) {
+            if (!ctxs[i]->p2p) return fail(ctxs[i], PHYLO_EINVAL, "the contexts of a group must use the same exchange");
+            CHK(comm_exchange(ctxs[i], rows.data() + 3 * (size_t)i, 3, (size_t)ctxs[i]->Kloc, 0));
+        }
+    } else {
         phylo_ctx* c0 = ctxs[0];
         std::vector<size_t> counts(n);
         for (int i = 0; i < n; ++i) counts[i] = (size_t)ctxs[i]->Kloc;
@@ -1627,8 +1706,7 @@ int phylo_sweep_node(phylo_ctx* c, int r, int k, double* out) {
             CHK(launch_check(c, "pk_materialize_rank"));
             c->last_graph_marks = false;                   // the marks now cover more than the adopted nodes
             if (c->comm.transport != 0) {
-                double* rows[1] = {c->d_sync};
-                CHK(phylo_comm_allgather_inplace(c->comm, rows, 1, 1, c->stream, &c->err));
+                CHK(comm_exchange(c, nullptr, 0, 0, 1));
             }
         }
         c->last_lazy = false;

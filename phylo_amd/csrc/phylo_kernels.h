@@ -2057,6 +2057,67 @@ __global__ void pk_twist_tables(const pk_twist_args ta) {
     a.cnt_new[(size_t)kg * N + p] = co[il] + co[ir];
 }
 
+// ================================================================================================
+// Multi-GPU, one process per GPU: the exchange of a rank event WITHOUT a collective call ("a one-shot P2P
+// write into peers' buffers + flag"; the RCCL all-gather of phylo_comm.h stays as the compare / fallback path, PHYLO_P2P=0).
+// Every rank owns an EXCHANGE SLAB (fine-grained device memory, the same layout on every rank, mapped by every peer through
+// hipIpc like the node pools): the K-vectors that are all-gathered (log-weights, log-likelihoods, node log-likelihoods, the
+// twisted proposal's choices) and one 64-bit flag per peer and purpose.  One workgroup per rank:
+//   1. copies THIS rank's segments of up to four arrays into every peer's slab over xGMI (system-scope write-through stores,
+//      consecutive lanes -> consecutive addresses), fence, workgroup barrier;
+//   2. stores the exchange's epoch (monotone per context; every rank issues the same exchanges in the same order) into its flag
+//      in every peer's slab (release, system scope);
+//   3. lanes poll the peers' flags in the OWN slab until they reach the epoch (bounded by wall-clock time: PK_P2P_WAIT_TICKS of
+//      the 100 MHz real-time counter, then the timeout word is set and phylo_sweep_fetch reports the sweep as invalid), one
+//      system-scope acquire, barrier.
+// A rank can be at most one exchange ahead of a peer (it needs the peer's flag of exchange e to finish e), and an array's row
+// is written again only N - 1 >= 2 exchanges later, so no row is overwritten before its readers are done (contexts of two
+// taxa, one exchange per sweep, use the collective).  With n_seg = 0 the kernel is a barrier (the "owners have written their
+// adopted nodes" barrier of lazy nodes).  No host call, no second stream, no communicator shared between contexts.
+// ================================================================================================
+#define PK_P2P_WAIT_TICKS 200000000ull       // 2 s of s_memrealtime (100 MHz)
+struct pk_p2p_args {
+    char* const* slabs;                      // [world] every rank's exchange slab as mapped in this process (own slab at [me])
+    int world, me;
+    int n_seg;                               // arrays to exchange (0: barrier only)
+    size_t seg_off[4];                       // byte offset of each array in the slab; rank p's segment starts at + p * seg_count doubles
+    int seg_count;                           // doubles per rank and array
+    size_t flag_off;                         // byte offset of this purpose's flags[world] (u64) in the slab
+    unsigned long long epoch;
+    unsigned int* timeout_word;
+};
+__global__ __launch_bounds__(1024) void pk_p2p_exchange(const pk_p2p_args a) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int per = a.n_seg * a.seg_count;
+    for (int p = 0; p < a.world; ++p) {
+        if (p == a.me) continue;
+        for (int i = tid; i < per; i += nt) {
+            const int seg = i / a.seg_count, e = i - seg * a.seg_count;
+            const size_t at = a.seg_off[seg] + ((size_t)a.me * a.seg_count + e) * 8;
+            const double v = *reinterpret_cast<const double*>(a.slabs[a.me] + at);      // written by this rank's previous kernel
+            __hip_atomic_store(reinterpret_cast<double*>(a.slabs[p] + at), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope
+    __syncthreads();
+    if (tid < a.world && tid != a.me)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.slabs[tid] + a.flag_off) + a.me, a.epoch, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < a.world && tid != a.me) {
+        const unsigned long long* f = reinterpret_cast<const unsigned long long*>(a.slabs[a.me] + a.flag_off) + tid;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > PK_P2P_WAIT_TICKS) {
+                __hip_atomic_store(a.timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");            // system scope
+    __syncthreads();
+}
+
 // arithmetic probe
 __global__ void pk_math_probe(int op, const double* __restrict__ x, const double* __restrict__ y, int n,
                               double* __restrict__ out) {

@@ -1,7 +1,8 @@
 """Sharded sweep on real hardware.  A one-GPU box cannot host several RCCL ranks (RCCL refuses duplicate
-devices), so several PROCESSES share GPU 0 and exchange the per-rank vectors through the hostshm transport
-(PHYLO_COMM=hostshm); the sharded bookkeeping, the node addressing and the hipIpc peer mappings of the node
-pools are the product's own.  The result must be bit-identical to the unsharded sweep and to the oracle.
+devices), so several PROCESSES share GPU 0; PHYLO_COMM=hostshm carries the host-side collectives (rendezvous of the hipIpc
+handles, phylo_comm_max).  The exchange of every rank event is the product's own device-side one (pk_p2p_exchange: writes
+into the peers' hipIpc-mapped slabs + flags; the default), or with PHYLO_P2P=0 the collective path (hostshm here, RCCL in
+production); the sharded bookkeeping, the node addressing and the hipIpc peer mappings of the node pools are the product's own.  The result must be bit-identical to the unsharded sweep and to the oracle.
 RCCL itself is exercised with a world of one rank."""
 import os
 import subprocess
@@ -45,14 +46,17 @@ def run_world(world, K, dataset, seed, jc, n_sweeps=1, transport='hostshm', extr
 
 
 @pytest.mark.parametrize("world,K,jc,form", [(2, 64, True, 'default'), (3, 96, False, 'default'), (2, 64, False, 'replicated'),
-                                             (2, 64, False, 'eager'), (3, 96, True, 'eager')])
+                                             (2, 64, False, 'eager'), (3, 96, True, 'eager'),
+                                             (2, 64, True, 'collective'), (3, 96, False, 'collective'), (2, 64, False, 'eager-collective')])
 def test_sharded_sweep_bit_identical(world, K, jc, form):
     """default: lazy nodes, every rank advances only its own particles' root tables and reads an adopted ancestor's rows
     from the owner's slab (peer mapping), adopted nodes are marked from the replicated index search and written by their
     owner before a barrier collective; eager (PHYLO_EAGER_NODES=1): every node stored, one collective per rank event;
     replicated (PHYLO_REPLICATED_BOOK=1): every rank advances all K tables redundantly."""
     dataset, seed, n_sweeps = 'primate_data', 4, 2
-    env = {'replicated': {'PHYLO_REPLICATED_BOOK': '1'}, 'eager': {'PHYLO_EAGER_NODES': '1'}}.get(form)
+    env = {'replicated': {'PHYLO_REPLICATED_BOOK': '1'}, 'eager': {'PHYLO_EAGER_NODES': '1'},
+           'collective': {'PHYLO_P2P': '0'},                # the all-gather per rank event instead of the device-side exchange
+           'eager-collective': {'PHYLO_EAGER_NODES': '1', 'PHYLO_P2P': '0'}}.get(form)
     parts = run_world(world, K, dataset, seed, jc, n_sweeps=n_sweeps, extra_env=env)
     g = load_dataset(dataset)['genome']
     N = g.shape[0]
@@ -92,11 +96,12 @@ def test_sharded_lazy_nodes_bit_identical():
         assert np.array_equal(p['node'].view(np.uint64), ref['nodes'][N - 2, (r + 1) * Kl - 1].view(np.uint64))
 
 
-def test_sharded_twisted_sweep_bit_identical():
+@pytest.mark.parametrize("p2p", ['1', '0'])
+def test_sharded_twisted_sweep_bit_identical(p2p):
     """Twisting when sharded: potentials are computed for local particles only, the chosen (pair, sub-sample)
-    of every particle travels with one more all-gather, then every rank updates all root tables."""
+    of every particle travels with one more exchange, then every rank updates all root tables."""
     world, K, M, seed = 2, 32, 2, 3
-    parts = run_world(world, K, 'primate_data_wang', seed, True, extra_env={'PHYLO_TEST_TWIST_M': str(M)})
+    parts = run_world(world, K, 'primate_data_wang', seed, True, extra_env={'PHYLO_TEST_TWIST_M': str(M), 'PHYLO_P2P': p2p})
     g = load_dataset('primate_data_wang')['genome']
     lam = np.full(8, 10.0)
     ref = CO.sweep_twisted(g, O.jc_Q(), PI, lam, lam, K, M, seed, jc=True)

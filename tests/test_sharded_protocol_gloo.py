@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _worker(rank, world, port, K, seed, tmp, local_tables, lazy):
+def _worker(rank, world, port, K, seed, tmp, local_tables, lazy, flags=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -63,10 +63,59 @@ def _worker(rank, world, port, K, seed, tmp, local_tables, lazy):
         def fetch_node(self, owner, key):
             return self.pools[owner][key]
 
+    class FlagComm(Comm):
+        """The device-side exchange of the GPU path (pk_p2p_exchange) as a protocol model: every rank owns a slab (a file
+        mapped by all ranks, like the hipIpc mappings) holding R rows of 3 x K doubles and two sets of flags; an exchange writes
+        this rank's segment of row r into EVERY peer's slab, then its flag (the monotone epoch of the exchange) in every peer's
+        slab, and waits until every peer's flag in the OWN slab has reached the epoch.  Rows are reused from sweep to sweep
+        (one epoch counter per purpose, as on the GPU); the barrier is the same exchange without a payload."""
+
+        def __init__(self, R):
+            super().__init__()
+            self.R, self.row, self.epoch = R, 0, [0, 0]
+            self.words = R * 3 * K + 2 * world
+            mine = np.memmap(os.path.join(tmp, 'slab%d.bin' % rank), dtype=np.float64, mode='w+', shape=(self.words,))
+            mine[:] = 0.0
+            mine.flush()
+            dist.barrier()
+            self.slabs = [np.memmap(os.path.join(tmp, 'slab%d.bin' % p), dtype=np.float64, mode='r+', shape=(self.words,))
+                          for p in range(world)]
+
+        def _flags(self, p, purpose):
+            return self.slabs[p][self.R * 3 * K + purpose * world:self.R * 3 * K + (purpose + 1) * world]
+
+        def _signal_and_wait(self, purpose):
+            import time
+            self.epoch[purpose] += 1
+            e = float(self.epoch[purpose])
+            for p in range(world):
+                if p != rank:
+                    self._flags(p, purpose)[rank] = e
+            t0 = time.time()
+            while any(self._flags(rank, purpose)[p] < e for p in range(world) if p != rank):
+                assert time.time() - t0 < 60, "flag wait timed out"
+                time.sleep(0)
+
+        def all_gather(self, arr):
+            r, Kl = self.row % self.R, arr.shape[1]
+            self.row += 1
+            for p in range(world):                           # my segment of the three vectors into every slab (my own included)
+                v = self.slabs[p][r * 3 * K:(r + 1) * 3 * K].reshape(3, K)
+                v[:, rank * Kl:(rank + 1) * Kl] = arr
+            self._signal_and_wait(0)
+            full = np.array(self.slabs[rank][r * 3 * K:(r + 1) * 3 * K].reshape(3, K))
+            return [full[:, p * Kl:(p + 1) * Kl] for p in range(world)]
+
+        def barrier(self):
+            self._signal_and_wait(1)
+
     g = load_dataset('primate_data_wang')['genome'][:, :120]
     N = g.shape[0]
     Q, pi, lam = O.get_Q(O.init_y_q()), np.full((1, 4), 0.25), np.full(N - 1, 10.0)
-    out = sweep_sharded(Comm(), rank, world, g, Q, pi, lam, lam, K, seed, local_tables=local_tables, lazy=lazy)
+    comm = FlagComm(N - 1) if flags else Comm()
+    if flags:                                                # a first sweep with another seed: the rows and flags are reused
+        sweep_sharded(comm, rank, world, g, Q, pi, lam, lam, K, seed + 1, local_tables=local_tables, lazy=lazy)
+    out = sweep_sharded(comm, rank, world, g, Q, pi, lam, lam, K, seed, local_tables=local_tables, lazy=lazy)
     ref = O.sweep(g, Q, pi, lam, lam, K, seed)
     np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
     np.testing.assert_allclose(out['log_weights'], ref['log_weights'], rtol=1e-12)
@@ -76,12 +125,16 @@ def _worker(rank, world, port, K, seed, tmp, local_tables, lazy):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("K,seed,local_tables,lazy", [(16, 0, False, False), (24, 3, True, False), (24, 5, True, True),
-                                                      (24, 5, True, 'draws'), (40, 9, True, 'draws')])
-def test_sharded_protocol_world2(K, seed, local_tables, lazy):
+@pytest.mark.parametrize("K,seed,local_tables,lazy,flags", [(16, 0, False, False, False), (24, 3, True, False, False),
+                                                            (24, 5, True, True, False), (24, 5, True, 'draws', False),
+                                                            (40, 9, True, 'draws', False), (24, 5, True, 'draws', True),
+                                                            (16, 2, False, False, True)])
+def test_sharded_protocol_world2(K, seed, local_tables, lazy, flags):
+    """flags=True: the all-gather and the barrier go through the slab-and-flag exchange (the GPU path's pk_p2p_exchange) over
+    files mapped by both processes; two sweeps in a row reuse rows and flags."""
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() * 7 + K) % 1000
+    port = 29500 + (os.getpid() * 7 + K + 13 * int(bool(flags))) % 1000
     with tempfile.TemporaryDirectory() as tmp:
-        mp.spawn(_worker, args=(2, port, K, seed, tmp, local_tables, lazy), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, K, seed, tmp, local_tables, lazy, flags), nprocs=2, join=True)
         fetched = sum(int(np.load(os.path.join(tmp, 'fetch%d.npy' % r))[0]) for r in range(2))
         assert fetched > 0, "the test never exercised a remote child"
