@@ -247,6 +247,10 @@ int phylo_comm_allgather(phylo_ctx* ctx, const void* mine, size_t bytes, void* a
  * host-mediated test transport gathers and takes the max on the host); identity when no communicator is set. */
 int phylo_comm_max(phylo_ctx* ctx, double* value);
 int phylo_comm_barrier(phylo_ctx* ctx);
+/* How this context exchanges the K-vectors of a rank event with the other ranks: 0 not sharded; 1 RCCL all-gather; 2 the
+ * host-mediated test transport (PHYLO_COMM=hostshm); 3 the device-side exchange (every rank writes into the peers' hipIpc-mapped
+ * slabs and raises a flag: no collective call per rank event; the default when sharded, PHYLO_P2P=0 turns it off). */
+int phylo_comm_exchange_kind(const phylo_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,7 @@ EXPORTS = [
     "phylo_math_probe", "phylo_debug_stamps", "phylo_debug_reverse_lists",
     "phylo_site_tile", "phylo_set_site_tile", "phylo_get_site_tile",
     "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_allgather", "phylo_comm_max", "phylo_comm_barrier",
+    "phylo_comm_exchange_kind",
 ]
 
 
@@ -335,6 +336,10 @@ class Context:
         out = np.empty((world,) + a.shape, dtype=a.dtype)
         self._check(self._lib.phylo_comm_allgather(self._h, _ptr(a), C.c_size_t(a.nbytes), _ptr(out)))
         return out
+
+    def comm_exchange_kind(self):
+        """'none' | 'rccl' | 'hostshm' | 'p2p': how the K-vectors of a rank event reach the other ranks"""
+        return ('none', 'rccl', 'hostshm', 'p2p')[int(self._lib.phylo_comm_exchange_kind(self._h))]
 
     def comm_max(self, value):
         v = C.c_double(float(value))

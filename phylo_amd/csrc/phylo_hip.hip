@@ -50,6 +50,8 @@ struct env_switches {
          persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, no_spin_wait = false,
          no_p2p = false;
     int persist_wgs = 0;                 // PHYLO_PERSIST_WGS: resident workgroups of the one-launch sweep (0 = default)
+    unsigned long long p2p_wait_ticks = PK_P2P_WAIT_TICKS;   // PHYLO_P2P_WAIT_S: bound of a flag wait of the device-side exchange
+    size_t p2p_copy_words = 65536;       // PHYLO_P2P_COPY_WORDS: exchanges beyond this many doubles copy with many workgroups (tests lower it)
     int persist_nt = 256;                // PHYLO_PERSIST_NT: threads per workgroup of the one-launch sweep (256 or 512)
     void read() {
         eager_nodes = getenv("PHYLO_EAGER_NODES") != nullptr;
@@ -66,6 +68,8 @@ struct env_switches {
         grad_two_streams = getenv("PHYLO_GRAD_TWO_STREAMS") != nullptr;
         no_spin_wait = getenv("PHYLO_NO_SPIN_WAIT") != nullptr;
         { const char* e = getenv("PHYLO_P2P"); no_p2p = e && atoi(e) == 0; }
+        { const char* e = getenv("PHYLO_P2P_COPY_WORDS"); p2p_copy_words = e ? (size_t)atol(e) : 65536; }
+        { const char* e = getenv("PHYLO_P2P_WAIT_S"); p2p_wait_ticks = e && atof(e) > 0 ? (unsigned long long)(atof(e) * 1e8) : PK_P2P_WAIT_TICKS; }
         const char* w = getenv("PHYLO_PERSIST_WGS");
         persist_wgs = w ? atoi(w) : 0;
         const char* t = getenv("PHYLO_PERSIST_NT");
@@ -1221,6 +1225,14 @@ static int comm_exchange(phylo_ctx* c, double* const* arrays, int n_arrays, size
     a.flag_off = c->x_flag_off[purpose];
     a.epoch = ++c->x_epoch[purpose];
     a.timeout_word = c->d_counter + 1;
+    a.wait_ticks = c->env.p2p_wait_ticks;
+    const size_t words = (size_t)n_arrays * count * (size_t)(c->world - 1);
+    if (words > c->env.p2p_copy_words) {                   // large exchange: the copy over many workgroups, then the flags alone
+        const size_t wgs = (words + 4095) / 4096;
+        hipLaunchKernelGGL(pk_p2p_copy, dim3((unsigned)(wgs < 512 ? wgs : 512)), dim3(1024), 0, c->stream, a);
+        CHK(launch_check(c, "pk_p2p_copy"));
+        a.n_seg = 0;
+    }
     hipLaunchKernelGGL(pk_p2p_exchange, dim3(1), dim3(1024), 0, c->stream, a);
     return launch_check(c, "pk_p2p_exchange");
 }
@@ -2228,6 +2240,11 @@ int phylo_comm_share(phylo_ctx* c, phylo_ctx* owner) {
     CHK(refresh_leaf_ll(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return PHYLO_OK;
+}
+
+int phylo_comm_exchange_kind(const phylo_ctx* c) {
+    if (!c || c->comm.transport == 0) return 0;
+    return c->p2p ? 3 : c->comm.transport;
 }
 
 int phylo_comm_max(phylo_ctx* c, double* value) {

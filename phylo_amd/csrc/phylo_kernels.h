@@ -2067,15 +2067,15 @@ __global__ void pk_twist_tables(const pk_twist_args ta) {
 //      consecutive lanes -> consecutive addresses), fence, workgroup barrier;
 //   2. stores the exchange's epoch (monotone per context; every rank issues the same exchanges in the same order) into its flag
 //      in every peer's slab (release, system scope);
-//   3. lanes poll the peers' flags in the OWN slab until they reach the epoch (bounded by wall-clock time: PK_P2P_WAIT_TICKS of
-//      the 100 MHz real-time counter, then the timeout word is set and phylo_sweep_fetch reports the sweep as invalid), one
+//   3. lanes poll the peers' flags in the OWN slab until they reach the epoch (bounded by wall-clock time: ten seconds of the
+//      100 MHz real-time counter unless PHYLO_P2P_WAIT_S says otherwise -- ranks may be apart by host work --, then the timeout word is set and phylo_sweep_fetch reports the sweep as invalid), one
 //      system-scope acquire, barrier.
 // A rank can be at most one exchange ahead of a peer (it needs the peer's flag of exchange e to finish e), and an array's row
 // is written again only N - 1 >= 2 exchanges later, so no row is overwritten before its readers are done (contexts of two
 // taxa, one exchange per sweep, use the collective).  With n_seg = 0 the kernel is a barrier (the "owners have written their
 // adopted nodes" barrier of lazy nodes).  No host call, no second stream, no communicator shared between contexts.
 // ================================================================================================
-#define PK_P2P_WAIT_TICKS 200000000ull       // 2 s of s_memrealtime (100 MHz)
+#define PK_P2P_WAIT_TICKS 1000000000ull      // default bound of a flag wait: 10 s of s_memrealtime (100 MHz); PHYLO_P2P_WAIT_S
 struct pk_p2p_args {
     char* const* slabs;                      // [world] every rank's exchange slab as mapped in this process (own slab at [me])
     int world, me;
@@ -2084,8 +2084,25 @@ struct pk_p2p_args {
     int seg_count;                           // doubles per rank and array
     size_t flag_off;                         // byte offset of this purpose's flags[world] (u64) in the slab
     unsigned long long epoch;
+    unsigned long long wait_ticks;           // bound of the flag wait in 100 MHz ticks
     unsigned int* timeout_word;
 };
+// the copy alone, over many workgroups (large exchanges: batched sweeps move 3 x 8 x Kloc bytes to every peer; one workgroup's
+// store issue would take longer than the merge): the kernel boundary behind it orders the writes before the flags that
+// pk_p2p_exchange (with n_seg = 0) then raises
+__global__ __launch_bounds__(1024) void pk_p2p_copy(const pk_p2p_args a) {
+    const long per = (long)a.n_seg * a.seg_count, total = per * (a.world - 1);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int p = (int)(i / per);
+        const long j = i - (long)p * per;
+        p += p >= a.me ? 1 : 0;                                  // the peers in rank order, this rank left out
+        const int seg = (int)(j / a.seg_count), e = (int)(j - (long)seg * a.seg_count);
+        const size_t at = a.seg_off[seg] + ((size_t)a.me * a.seg_count + e) * 8;
+        const double v = *reinterpret_cast<const double*>(a.slabs[a.me] + at);
+        __hip_atomic_store(reinterpret_cast<double*>(a.slabs[p] + at), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ __launch_bounds__(1024) void pk_p2p_exchange(const pk_p2p_args a) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int per = a.n_seg * a.seg_count;
@@ -2108,7 +2125,7 @@ __global__ __launch_bounds__(1024) void pk_p2p_exchange(const pk_p2p_args a) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.epoch) {
             __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > PK_P2P_WAIT_TICKS) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.wait_ticks) {
                 __hip_atomic_store(a.timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }

@@ -160,13 +160,16 @@ def test_sweeps_in_flight_share_one_communicator(transport, world, extra):
         assert np.array_equal(p['node'].view(np.uint64), ref_last['nodes'][N - 2, (r + 1) * Kl - 1].view(np.uint64))
 
 
-@pytest.mark.parametrize("world,G,Kg", [(2, 3, 32), (3, 2, 48)])
-def test_batched_sweeps_on_sharded_contexts(world, G, Kg):
+@pytest.mark.parametrize("world,G,Kg,copy_words", [(2, 3, 32, None), (3, 2, 48, None), (3, 2, 48, '64')])
+def test_batched_sweeps_on_sharded_contexts(world, G, Kg, copy_words):
     """G independent sweeps in ONE sharded context: the G * Kg particle indices are sharded by contiguous ranges (a
     group straddles ranks when world does not divide G), one all-gather per rank event carries all of them, and
     every group is bit for bit the Kg-particle sweep of its seed."""
     seed = 6
-    parts = run_world(world, G * Kg, 'primate_data', seed, False, n_sweeps=2, extra_env={'PHYLO_TEST_BATCH': str(G)})
+    env = {'PHYLO_TEST_BATCH': str(G)}
+    if copy_words:                                         # the large-exchange form: copy over many workgroups, then the flags alone
+        env['PHYLO_P2P_COPY_WORDS'] = copy_words
+    parts = run_world(world, G * Kg, 'primate_data', seed, False, n_sweeps=2, extra_env=env)
     g = load_dataset('primate_data')['genome']
     N = g.shape[0]
     Q = O.get_Q(O.init_y_q())
