@@ -28,7 +28,10 @@ def parse_args(argv=None):
     parser.add_argument('--jcmodel', default=False, type=lambda x: (str(x).lower() == 'true'))
     parser.add_argument('--memory_optimization', help='Use memory optimization?', default='on')
     parser.add_argument('--seed', type=int, default=0, help='seed of the counter-based RNG contract')
-    parser.add_argument('--n_gpus', type=int, default=1)
+    parser.add_argument('--n_gpus', type=int, default=1,
+                        help='one process per GPU (python -m torch.distributed.run --nproc-per-node N runner.py --n_gpus N ...): the '
+                             'particles of the EVALUATION sweeps are sharded over the ranks (global resampling, same bits as one GPU); '
+                             'the optimiser steps are not sharded: every rank takes the same step on its own device')
     parser.add_argument('--ambiguity', choices=('error', 'iupac'), default='error',
                         help="characters outside the dataset's alphabet: KeyError like the reference, or IUPAC indicator rows")
     args = parser.parse_args(argv)

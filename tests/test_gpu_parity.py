@@ -218,7 +218,9 @@ def test_sweep_quirk_flag_and_trained_like_model():
 
 
 def test_sweep_full_size_properties(primate):
-    """BASELINE sizes (primate.p, K=2048): size-independent properties instead of a slow oracle run."""
+    """BASELINE sizes (primate.p, K=2048): size-independent properties of one sweep (checksum of checksums, indices reproduced
+    from the returned weights, valid merges).  The bit-for-bit comparison at this size is
+    tests/test_gpu_fullsize.py::test_primate_gtr_K2048_ten_seeds."""
     K, N = 2048, 12
     Q = O.get_Q(O.init_y_q())
     ctx = make_ctx(primate, K, Q)
