@@ -50,6 +50,30 @@ __device__ __forceinline__ double pk_readlane(double v, int l) {      // l wave-
     hi = __builtin_amdgcn_readlane(hi, l);
     return __hiloint2double(hi, lo);
 }
+// Scalar-cache touch.  A wave's start-up is a chain of scalar-load round trips (kernel arguments -> ids -> matrices -> pi -> first
+// rows), and hipcc requests a wave-uniform matrix only where it is first used, behind the branches on the ids (requested earlier
+// its 32-64 scalar registers would live across those branches: spills).  PK_TOUCH_* issue one-dword scalar loads of the
+// matrix's cache lines BESIDE the load of the ids, so the real loads hit the scalar cache: headline +4.4 %, single sweep -1 %
+// (A/B/A/B on one box).  The dummy destination registers must not get a new owner while a touch is in flight, on ANY path:
+// PK_TOUCH_END(ids) waits for scalar memory and passes the ids THROUGH (an in-out operand), so it sits before every use of the
+// ids -- i.e. on every path, before the first branch on them -- and reads the dummies, which keeps them reserved from the touch
+// to the wait.  Neither asm is volatile: a volatile asm counts as a store, after which hipcc no longer proves uniform loads
+// invariant and turns the matrices' scalar loads into vector loads (32 more VGPRs, scratch).  (First version: a consumer after
+// the matrices' loads and without the wait -- on the paths that did not reach it hipcc gave the dummies' registers to its own
+// loads while the touches were in flight, and the twisted sweep faulted.)
+#ifndef PK_NO_SCALAR_TOUCH
+#define PK_TOUCH_DECL unsigned int pk_t0_, pk_t1_, pk_t2_, pk_t3_, pk_t4_, pk_t5_
+#define PK_TOUCH_256_2(p256, q, r)                                                                                              \
+    asm("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\ts_load_dword %3, %6, 0xc0\n\t"      \
+        "s_load_dword %4, %7, 0x0\n\ts_load_dword %5, %8, 0x0"                                                                 \
+        : "=&s"(pk_t0_), "=&s"(pk_t1_), "=&s"(pk_t2_), "=&s"(pk_t3_), "=&s"(pk_t4_), "=&s"(pk_t5_) : "s"(p256), "s"(q), "s"(r))
+#define PK_TOUCH_END(x) asm("s_waitcnt lgkmcnt(0)" : "+s"(x) : "s"(pk_t0_), "s"(pk_t1_), "s"(pk_t2_), "s"(pk_t3_), "s"(pk_t4_), "s"(pk_t5_))
+#else
+#define PK_TOUCH_DECL
+#define PK_TOUCH_256_2(p256, q, r)
+#define PK_TOUCH_END(x)
+#endif
+
 __device__ __forceinline__ double pk_wave_tree_sum(double v) {
     v = v + pk_dpp<0xB1>(v);          // quad_perm [1,0,3,2]: xor 1
     v = v + pk_dpp<0x4E>(v);          // quad_perm [2,3,0,1]: xor 2
@@ -1599,13 +1623,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 8))) void
     const int item = (int)blockIdx.x, ntiles = a.ntiles;
     const int k = ntiles == 1 ? item : item / ntiles, tau = item - k * ntiles;
     const int s0 = tau * a.T, s1 = s0 + a.T < a.S ? s0 + a.T : a.S;
-    const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
+    const double* Pu = a.Pmat + (size_t)k * 32;
+    PK_TOUCH_DECL;
+    PK_TOUCH_256_2(Pu, a.pi, a.aux + (size_t)k * PK_AUX);        // both matrices, pi, the epilogue's weight terms
+    int cl = a.child[k * 2];
+    const int cr = a.child[k * 2 + 1];
+    PK_TOUCH_END(cl);                                      // (before the first use of the children, on every path)
     const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // wave-uniform
     const double* Lp = pk_node_ptr(a, cl);
     const double* Rp = pk_node_ptr(a, cr);
     const uint8_t* Lc = a.leaf_codes + (codedL ? (size_t)cl * a.S : 0);
     const uint8_t* Rc = a.leaf_codes + (codedR ? (size_t)cr * a.S : 0);
-    const double* Pu = a.Pmat + (size_t)k * 32;
     double Pl[16], Pr[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) { Pl[u] = Pu[u]; Pr[u] = Pu[16 + u]; }   // uniform address, nothing stored yet: scalar loads
@@ -1709,14 +1737,18 @@ __global__ __launch_bounds__(PK_COLS) __attribute__((amdgpu_waves_per_eu(5, 8)))
     const int s0 = tau * a.T, s1 = s0 + a.T < a.S ? s0 + a.T : a.S, len = s1 - s0;
     double* likbuf = pk_lds_dyn;
     double* stage = pk_lds_dyn + ((len + 1) & ~1) + (size_t)wv * 256;
-    const int cl = a.child[k * 2], cr = a.child[k * 2 + 1];
+    const double* Pu = a.Pmat + (size_t)k * 32;
+    PK_TOUCH_DECL;
+    PK_TOUCH_256_2(Pu, a.pi, a.aux + (size_t)k * PK_AUX);
+    int cl = a.child[k * 2];
+    const int cr = a.child[k * 2 + 1];
+    PK_TOUCH_END(cl);
     const bool codedL = a.leaf_codes && cl < a.N, codedR = a.leaf_codes && cr < a.N;   // workgroup-uniform
     const double* Lp = pk_node_ptr(a, cl);
     const double* Rp = pk_node_ptr(a, cr);
     const uint8_t* Lc = a.leaf_codes + (codedL ? (size_t)cl * a.S : 0);
     const uint8_t* Rc = a.leaf_codes + (codedR ? (size_t)cr * a.S : 0);
     double* out = a.pool + ((size_t)a.r * a.Kloc + k) * (size_t)a.S * 4;
-    const double* Pu = a.Pmat + (size_t)k * 32;
     double Pl[16], Pr[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) { Pl[u] = Pu[u]; Pr[u] = Pu[16 + u]; }   // uniform address: scalar loads
@@ -1839,10 +1871,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
     while (rem >= n - 1 - r1) { rem -= n - 1 - r1; ++r1; }
     const int r2 = r1 + 1 + rem;
     const int32_t* ro = ta.roots_ad + (size_t)kg * a.N;
-    const int idl = ro[r1], idr = ro[r2];
+    const double* P = ta.tw_P + ((size_t)k * J + j) * 32;      // wave-uniform: scalar loads
+    PK_TOUCH_DECL;
+    PK_TOUCH_256_2(P, a.pi, ta.cnt_ad + (size_t)kg * a.N);     // the row's matrices, pi, the epilogue's leaf counts: beside the root ids
+    int idl = ro[r1];
+    const int idr = ro[r2];
+    PK_TOUCH_END(idl);                                         // (before the first use of the ids, on every path)
     const bool leafL = idl < a.N, leafR = idr < a.N;
     if (ta.pair_hist && leafL && leafR) return;                // coded leaf x coded leaf: pk_twist_potentials_ll
-    const double* P = ta.tw_P + ((size_t)k * J + j) * 32;      // wave-uniform: scalar loads
     const double* Lp = pk_node_ptr(a, idl);
     const double* Rp = pk_node_ptr(a, idr);
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
