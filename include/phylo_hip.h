@@ -151,7 +151,7 @@ int phylo_log_zsmc(phylo_ctx* ctx, const double* logw_RxK, int R, int K, double*
  *   ancestors : [(N-2), K]     resampling indices drawn before rank events 1..N-2 (global indices)
  *   logZ      : scalar; perf : timing of this sweep
  * M is the number of sub-samples of the twisted proposal (ignored without PHYLO_TWISTING; 1 <= M <= 1024,
- * C(N,2)*M <= 2^20 and (N-1)*M <= 32767 with it; beyond 8192 sub-samples per particle their weights leave LDS).  With PHYLO_TWISTING the weight subtracts the normalised log-potential of the
+ * C(N,2)*M <= 2^20 with it; beyond 8192 sub-samples per particle their weights leave LDS).  With PHYLO_TWISTING the weight subtracts the normalised log-potential of the
  * chosen (pair, sub-sample) (vncsmc.py:315-316,491) and merges[r,k] = (r1 < r2). */
 int phylo_sweep(phylo_ctx* ctx, uint64_t seed, uint32_t flags, int M, double* log_weights,
                 double* log_lik, double* lbranch, double* rbranch, int32_t* merges, int64_t* ancestors,

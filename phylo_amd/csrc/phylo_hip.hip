@@ -938,7 +938,6 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
         if (M < 1 || M > PK_TWIST_MAX_M) return fail(c, PHYLO_EINVAL, "twisting needs 1 <= M <= %d (got %d)", PK_TWIST_MAX_M, M);
         const size_t Jmax = (size_t)(N * (N - 1) / 2) * M;
         if (Jmax > PK_TWIST_MAX_J) return fail(c, PHYLO_EINVAL, "twisting: C(N,2)*M = %zu exceeds %d", Jmax, PK_TWIST_MAX_J);
-        if ((N - 1) * M > PK_TWIST_MAX_ROWS) return fail(c, PHYLO_EINVAL, "twisting: (N-1)*M = %d exceeds %d", (N - 1) * M, PK_TWIST_MAX_ROWS);
         if (Jmax > PK_TWIST_LDS_J && c->twbuf_cap < (size_t)Kl * Jmax) {     // weights of more sub-samples than LDS holds
             if (c->d_twbuf) (void)hipFree(c->d_twbuf);
             c->d_twbuf = nullptr;

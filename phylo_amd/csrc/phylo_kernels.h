@@ -1259,19 +1259,6 @@ __global__ __launch_bounds__(PK_COLS) void pk_rank_scan_book(const pk_rank_args 
     }
 }
 
-__device__ __forceinline__ double pk_dpp_even(double v) {   // the value held by the even lane of my pair
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, 0xA0, 0xF, 0xF, true);       // quad_perm [0,0,2,2]
-    hi = __builtin_amdgcn_mov_dpp(hi, 0xA0, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double pk_dpp_odd(double v) {    // the value held by the odd lane of my pair
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, 0xF5, 0xF, 0xF, true);       // quad_perm [1,1,3,3]
-    hi = __builtin_amdgcn_mov_dpp(hi, 0xF5, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-
 __device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int id) {
     const size_t node_sz = (size_t)a.S * 4;
     // a child is a leaf (id < N, replicated on every GPU) or the node id = N + rho*K + kappa created at rank
@@ -1784,8 +1771,6 @@ __global__ __launch_bounds__(PK_COLS) __attribute__((amdgpu_waves_per_eu(5, 8)))
     }
 }
 
-#define PK_TWIST_LDS_ROWS 8              // (pair, sub-sample) rows staged and reduced per pass
-#define PK_TWIST_MAX_ROWS 32767          // (N-1) M of one workgroup: its row list is dynamic LDS, 2 bytes per row
 
 // (leaf row of `code` . P)[j], bit-identical to pk_build_leaf_table
 __device__ __forceinline__ double pk_leaf_entry(const double* __restrict__ P, int code, int j) {

@@ -1,6 +1,6 @@
 """Random (N, S, K, model, flags, form) draws, GPU against the C oracle, bit for bit; wider ranges than the test suite's 60 draws
 (up to 70 taxa: the 16 / 32 / 64-lane and the wave-per-particle bookkeeping; batched groups; twisting; one-launch form; flat
-weights).  python tests/fuzz_parity.py [seconds] [seed]"""
+weights; site tiles from 64 sites to the default, rows of one to nine tiles).  python tests/fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -23,12 +23,15 @@ def bits(a, b):
 t0, n, kinds, last = time.time(), 0, {}, time.time()
 while time.time() - t0 < budget:
     N = int(rng.choice([2, 3, 5, 9, 12, 16, 17, 27, 32, 33, 40, 50, 64, 65, 70]))
-    S = int(rng.choice([1, 7, 64, 255, 256, 257, 600, 1025]))
+    S = int(rng.choice([1, 7, 63, 64, 65, 255, 256, 257, 600, 1025, 2049, 4100]))
+    T = int(rng.choice([0, 0, 64, 128, 448, 1024]))           # contract v5's site tile (0: the default); the oracle takes the same
     mode = str(rng.choice(['plain', 'plain', 'batched', 'twist', 'one_launch', 'eager', 'flat']))
     Kg = int(rng.choice([1, 3, 16, 50, 129, 256, 700]))
     G = int(rng.choice([2, 3, 5])) if mode == 'batched' else 1
     if mode == 'twist':
         N, Kg = min(N, 12), min(Kg, 50)
+    if S > 2048:
+        N, Kg = min(N, 17), min(Kg, 50)                       # (the oracle's K-replicated core)
     M = int(rng.choice([1, 2, 5])) if mode == 'twist' else 1
     jc = bool(rng.integers(0, 2))
     q1 = bool(rng.integers(0, 2))
@@ -54,8 +57,10 @@ while time.time() - t0 < budget:
     flags = (_ffi.QUIRK_Q1_RAW_Q if q1 else 0) | (_ffi.EAGER_NODES if mode == 'eager' else 0) | (_ffi.ONE_LAUNCH if mode == 'one_launch' else 0)
     oflags = O.QUIRK_Q1_RAW_Q if q1 else 0
     seeds = [int(rng.integers(0, 2 ** 40)) for _ in range(G)]
-    what = "N=%d S=%d mode=%s G=%d Kg=%d M=%d jc=%s q1=%s" % (N, S, mode, G, Kg, M, jc, q1)
+    what = "N=%d S=%d T=%d mode=%s G=%d Kg=%d M=%d jc=%s q1=%s" % (N, S, T, mode, G, Kg, M, jc, q1)
+    CO.set_site_tile(T)
     with _ffi.Context(G * Kg, N, S) as ctx:
+        ctx.set_site_tile(T)
         ctx.set_leaves(g)
         ctx.set_model(Q, pi, lam_l, lam_r, jc69_closed_form=jc)
         if mode == 'twist':
