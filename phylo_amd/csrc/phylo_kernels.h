@@ -61,12 +61,14 @@ __device__ __forceinline__ double pk_readlane(double v, int l) {      // l wave-
 // invariant and turns the matrices' scalar loads into vector loads (32 more VGPRs, scratch).  (First version: a consumer after
 // the matrices' loads and without the wait -- on the paths that did not reach it hipcc gave the dummies' registers to its own
 // loads while the touches were in flight, and the twisted sweep faulted.)
+__device__ __forceinline__ const char* pk_uniform_ptr(const void* p);
 #ifndef PK_NO_SCALAR_TOUCH
 #define PK_TOUCH_DECL unsigned int pk_t0_, pk_t1_, pk_t2_, pk_t3_, pk_t4_, pk_t5_
 #define PK_TOUCH_256_2(p256, q, r)                                                                                              \
     asm("s_load_dword %0, %6, 0x0\n\ts_load_dword %1, %6, 0x40\n\ts_load_dword %2, %6, 0x80\n\ts_load_dword %3, %6, 0xc0\n\t"      \
         "s_load_dword %4, %7, 0x0\n\ts_load_dword %5, %8, 0x0"                                                                 \
-        : "=&s"(pk_t0_), "=&s"(pk_t1_), "=&s"(pk_t2_), "=&s"(pk_t3_), "=&s"(pk_t4_), "=&s"(pk_t5_) : "s"(p256), "s"(q), "s"(r))
+        : "=&s"(pk_t0_), "=&s"(pk_t1_), "=&s"(pk_t2_), "=&s"(pk_t3_), "=&s"(pk_t4_), "=&s"(pk_t5_)                             \
+        : "s"(pk_uniform_ptr(p256)), "s"(pk_uniform_ptr(q)), "s"(pk_uniform_ptr(r)))   /* (readfirstlane: a uniform value may live in VGPRs) */
 #define PK_TOUCH_END(x) asm("s_waitcnt lgkmcnt(0)" : "+s"(x) : "s"(pk_t0_), "s"(pk_t1_), "s"(pk_t2_), "s"(pk_t3_), "s"(pk_t4_), "s"(pk_t5_))
 #else
 #define PK_TOUCH_DECL
@@ -1524,6 +1526,9 @@ __device__ __forceinline__ void pk_rows_run(int s0, int s1, const char* bl, cons
     // steps in flight 39.8 (38.8 at five waves per SIMD).  hipcc sinks B's loads into B's uniform branch and waits for them
     // there, and that is still the fastest: with seven or eight waves per SIMD the launch is bound by instruction issue, not
     // by an exposed load, so the step and the selects that are not executed count for more than the load that is not in flight.
+    // Also measured (round 3, 40 960-particle launch): the complete trips peeled off into a loop without validity selects and
+    // clamps, both steps unconditional there: 72 against 63 us, single sweep 0.291 against 0.271 ms -- again hipcc interleaves the
+    // two steps and waits for both steps' rows at the top.
     #pragma unroll 1
     for (int u = s0; u < s1; u += 128, s += 128) {          // u: wave-uniform
         pk_rows_load<CL, CR>(B, bl, br, s + 64, s1);
