@@ -16,10 +16,16 @@ def _dir():
     return os.path.join(os.environ.get('PHYLO_RDZV_DIR', '/tmp'), "phylo_rdzv_" + tag)
 
 
+_calls = 0
+
+
 def exchange_comm_id(rank, world, make_id, timeout=300.0):
-    """rank 0 calls make_id() and publishes it; every rank returns the same bytes."""
+    """rank 0 calls make_id() and publishes it; every rank returns the same bytes.  Every call of a process uses its own file
+    (all ranks make the same calls in the same order), so a second communicator of the same run never reads the first one's id."""
+    global _calls
     d = _dir()
-    path = os.path.join(d, "comm_id.bin")
+    path = os.path.join(d, "comm_id_%d.bin" % _calls)
+    _calls += 1
     if rank == 0:
         cid = make_id()
         os.makedirs(d, exist_ok=True)
