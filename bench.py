@@ -94,7 +94,7 @@ def vi_step_timing(g, K, device=0, steps=12):
     for name, nested in (("plain", False), ("twisted_M1", True)):
         v = T.Variables(N, np.log(10.0), False)
         tr = T.Trainer(g, K, v, T.make_optimizer('Adam', 0.01), S, device=device, nested=nested, M=1)
-        fw, bw, wall, hostms = [], [], [], []
+        fw, bw, wall, hostms, who = [], [], [], [], "host"
         try:
             for i in range(steps + 3):
                 t0 = time.perf_counter()
@@ -103,10 +103,13 @@ def vi_step_timing(g, K, device=0, steps=12):
                 if i >= 3:
                     fw.append(tr.last['raw']['forward_ms']); bw.append(tr.last['raw']['backward_ms']); wall.append((t1 - t0) * 1e3)
                     hostms.append(tr.last['raw'].get('backward_host_ms', 0.0))
+                    who = tr.last['raw'].get('backward_lists', 'host')
         finally:
             tr.close()
-        out[name] = {"sweep_ms": float(np.median(fw)), "reverse_ms": float(np.median(bw)), "reverse_host_lists_ms": float(np.median(hostms)),
-                     "step_wall_ms": float(np.median(wall))}
+        # reverse_lists: who builds the reverse pass's integer lists -- "device" (kernels, phylo_revlists_dev.h: lists_host_ms is then the
+        # host's wait for ~50 integers) or "host" (twisted proposal, S > 4096: lists_host_ms is the time of the builders)
+        out[name] = {"sweep_ms": float(np.median(fw)), "reverse_ms": float(np.median(bw)), "reverse_lists": who,
+                     "reverse_lists_host_ms": float(np.median(hostms)), "step_wall_ms": float(np.median(wall))}
     return out
 
 

@@ -226,6 +226,17 @@ int phylo_debug_reverse_lists(int N, int K, const int64_t* ancestors, const int3
                               const int32_t* lookahead_nodes, int n_lookahead, int32_t* lists, int64_t n_lists, int32_t* meta,
                               int n_meta);
 
+/* The same lists built by the device kernels (phylo_revlists_dev.h) from the graph of the preceding lazy sweep with
+ * PHYLO_KEEP_GRAPH, copied back in the same layout (what the builders do not write reads -1; heavy[] holds GLOBAL chunk indices,
+ * rank_chunk0 in meta is zero), plus, when not NULL, the ancestors [N-2][K] and children [N-1][K][2] they were built from:
+ * tests/test_gpu_grad.py compares them with phylo_debug_reverse_lists on those. */
+int phylo_debug_device_lists(phylo_ctx* ctx, int32_t* lists, int64_t n_lists, int32_t* meta, int n_meta, int64_t* ancestors,
+                             int32_t* child);
+/* ... and from a genealogy the caller gives (the context's N and K; it replaces the last sweep's: sweep again before the next
+ * phylo_sweep_backward): tests/test_gpu_grad.py replays the cases of tests/test_revlists_cpu.py through the device builders. */
+int phylo_debug_device_lists_of(phylo_ctx* ctx, const int64_t* ancestors, const int32_t* child, int32_t* lists, int64_t n_lists,
+                                int32_t* meta, int n_meta);
+
 /* Bit-level probe of the device arithmetic contract: op 0 exp(x), 1 log(x), 2 x/y, 3 fma(x,y,x). */
 int phylo_math_probe(phylo_ctx* ctx, int op, const double* x, const double* y, int n, double* out);
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "phylo_forest_loglik", "phylo_tree_loglik", "phylo_resample", "phylo_log_zsmc", "phylo_sweep",
     "phylo_sweep_async", "phylo_sweep_batch_async", "phylo_sweep_batch_begin", "phylo_sweep_fetch_logz", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_step_a", "phylo_sweep_step_group", "phylo_sweep_finish", "phylo_sweep_fetch",
     "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
-    "phylo_math_probe", "phylo_debug_stamps", "phylo_debug_reverse_lists",
+    "phylo_math_probe", "phylo_debug_stamps", "phylo_debug_reverse_lists", "phylo_debug_device_lists", "phylo_debug_device_lists_of",
     "phylo_site_tile", "phylo_set_site_tile", "phylo_get_site_tile",
     "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_allgather", "phylo_comm_max", "phylo_comm_barrier",
     "phylo_comm_exchange_kind",
@@ -91,6 +91,12 @@ def debug_reverse_lists(N, K, ancestors, child, early_free=True, rows_form=True,
                                        C.c_int(meta.size))
     if rc:
         raise PhyloError(rc, lib.phylo_last_error(None).decode())
+    return _lists_dict(lists, meta, R, K)
+
+
+def _lists_dict(lists, meta, R, K):
+    nn = R * K
+    cap = 2 * nn // 4 + 1
     out = {}
     o = 0
     for name, n in (("ad_off", R * (K + 1)), ("ad_idx", nn), ("par_off", nn + 1), ("par_idx", 2 * nn), ("heavy", nn), ("chunk_beg", cap),
@@ -292,8 +298,34 @@ class Context:
         self._check(self._lib.phylo_sweep_backward(self._h, _ptr(out['d_lam_l']), _ptr(out['d_lam_r']), _ptr(out['d_pi']),
                                                    _ptr(out['d_Q']), C.byref(st)))
         out['backward_ms'] = st.sweep_ms
-        out['backward_host_ms'] = st.merge_ms          # host time of the integer lists inside backward_ms
+        out['backward_host_ms'] = st.merge_ms          # host time of the integer lists inside backward_ms (built, or waited for)
+        out['backward_lists'] = 'device' if st.merge_launches else 'host'   # who built them (phylo_revlists_dev.h / phylo_revlists.h)
         out['backward_launches'] = st.n_launches
+        return out
+
+    def debug_device_lists(self, ancestors=None, child=None):
+        """The reverse pass's integer lists as the device kernels build them from the last (lazy, KEEP_GRAPH, plain proposal) sweep,
+        or from the genealogy given (ancestors [N-2][K], child [N-1][K][2]; the context then needs a new sweep before the next
+        sweep_backward): the dict of debug_reverse_lists plus 'ancestors' and 'child' they were built from."""
+        R, K = self.N - 1, self.K
+        nn = R * K
+        cap = 2 * nn // 4 + 1
+        n_lists = R * (K + 1) + 9 * nn + 1 + 2 * cap
+        lists = np.zeros(n_lists, dtype=np.int32)
+        meta = np.zeros(6 + 3 * (R + 1), dtype=np.int32)
+        if child is not None:
+            anc = np.ascontiguousarray(ancestors if R > 1 else np.zeros((0, K)), dtype=np.int64).reshape(max(R - 1, 0), K)
+            child = np.ascontiguousarray(child, dtype=np.int32).reshape(R, K, 2)
+            self._check(self._lib.phylo_debug_device_lists_of(self._h, _ptr(anc) if R > 1 else None, _ptr(child), _ptr(lists),
+                                                              C.c_int64(n_lists), _ptr(meta), C.c_int(meta.size)))
+        else:
+            anc = np.zeros((max(R - 1, 0), K), dtype=np.int64)
+            child = np.zeros((R, K, 2), dtype=np.int32)
+            self._check(self._lib.phylo_debug_device_lists(self._h, _ptr(lists), C.c_int64(n_lists), _ptr(meta), C.c_int(meta.size),
+                                                           _ptr(anc) if R > 1 else None, _ptr(child)))
+        out = _lists_dict(lists, meta, R, K)
+        out['ancestors'] = anc
+        out['child'] = child
         return out
 
     def debug_stamps(self):

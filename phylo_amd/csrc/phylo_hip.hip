@@ -2,13 +2,14 @@
 // One context = one GPU, one stream.  No CPU fallback: without a HIP device every entry point fails.
 #include "../../include/phylo_hip.h"
 
+#include <cstring>                     // (ahead of the HIP headers: rocPRIM's use memcpy unqualified)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <rocprim/device/device_radix_sort.hpp>   // the two sorts of phylo_revlists_dev.h
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -18,6 +19,7 @@
 #include "phylo_kernels.h"
 #include "phylo_persist.h"
 #include "phylo_grad.h"
+#include "phylo_revlists_dev.h"
 
 namespace {
 
@@ -47,7 +49,7 @@ struct sweep_run {                       // a sweep being issued rank event by r
 struct env_switches {
     bool eager_nodes = false, rehearse_sharded = false, replicated_book = false, fuse_scan = false,
          book_one_per_wave = false, merge_pair_form = false, no_leaf_codes = false, one_launch = false,
-         persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, no_spin_wait = false,
+         persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, rev_host_lists = false, no_spin_wait = false,
          no_p2p = false;
     int persist_wgs = 0;                 // PHYLO_PERSIST_WGS: resident workgroups of the one-launch sweep (0 = default)
     unsigned long long p2p_wait_ticks = PK_P2P_WAIT_TICKS;   // PHYLO_P2P_WAIT_S: bound of a flag wait of the device-side exchange
@@ -66,6 +68,7 @@ struct env_switches {
         separate_materialise = getenv("PHYLO_SEPARATE_MATERIALISE") != nullptr;
         grad_one_stream = getenv("PHYLO_GRAD_ONE_STREAM") != nullptr;
         grad_two_streams = getenv("PHYLO_GRAD_TWO_STREAMS") != nullptr;
+        rev_host_lists = getenv("PHYLO_REV_HOST_LISTS") != nullptr;
         no_spin_wait = getenv("PHYLO_NO_SPIN_WAIT") != nullptr;
         { const char* e = getenv("PHYLO_P2P"); no_p2p = e && atoi(e) == 0; }
         { const char* e = getenv("PHYLO_P2P_COPY_WORDS"); p2p_copy_words = e ? (size_t)atol(e) : 65536; }
@@ -175,6 +178,12 @@ struct phylo_ctx {
     double* h_leaves_p = nullptr;        // pinned image of the leaf rows and their codes (phylo_set_leaves)
     hipEvent_t ev_leaves = nullptr;
     uint32_t *h_pub = nullptr, *hd_pub = nullptr;
+    int32_t *h_dlmeta = nullptr, *hd_dlmeta = nullptr;   // what pg_dl_lists tells the host (phylo_revlists_dev.h), pinned
+    hipEvent_t ev_dl = nullptr;
+    size_t dl_temp_p = 0, dl_temp_nn = 0;   // rocPRIM's temporary storage for the parents' sort at this R K
+    hipGraphExec_t dl_graph = nullptr;     // that sort's launches, captured (dev_lists_launch)
+    const void* dl_graph_key[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool dl_no_graph = false;
     uint32_t *hd_csr = nullptr, *hd_anc = nullptr, *hd_child = nullptr, *hd_rad = nullptr;   // device views of h_csr_p, h_anc_p, h_child_p, h_rad_p
     int32_t *h_child_p = nullptr, *h_rad_p = nullptr, *h_csr_p = nullptr;   // [R][K][2], [R][K][N] (twisted), the d_ad_off slab
     size_t h_csr_cap = 0;                // int32 elements
@@ -192,7 +201,7 @@ struct phylo_ctx {
     sweep_run run;
     int n_merge_events = 0;
     // grow-only scratch for the op-level entry points
-    DevBuf scratch[8];
+    DevBuf scratch[12];                  // (8..10: the device-built lists of the reverse pass)
     phylo_comm comm;
 };
 
@@ -312,6 +321,12 @@ void free_sweep_state(phylo_ctx* c) {
     if (c->h_child_p) (void)hipHostFree(c->h_child_p);
     if (c->h_rad_p) (void)hipHostFree(c->h_rad_p);
     if (c->h_pub) (void)hipHostFree(c->h_pub);
+    if (c->h_dlmeta) (void)hipHostFree(c->h_dlmeta);
+    c->h_dlmeta = c->hd_dlmeta = nullptr;
+    if (c->ev_dl) (void)hipEventDestroy(c->ev_dl);
+    c->ev_dl = nullptr;
+    if (c->dl_graph) (void)hipGraphExecDestroy(c->dl_graph);
+    c->dl_graph = nullptr;
     c->h_pub = c->hd_pub = nullptr;
     c->h_csr_p = c->h_child_p = c->h_rad_p = nullptr;
     c->h_anc_p = nullptr;
@@ -463,6 +478,10 @@ int ensure_graph_state(phylo_ctx* c) {
         HIPCHK(c, hipHostMalloc((void**)&c->h_pub, 16));   // log Z-hat (8 bytes) and the timeout word of a sweep that keeps its graph
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_pub, c->h_pub, 0));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_gcopy, hipEventDisableTiming));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_dlmeta, (size_t)PG_DL_META_INTS(R) * 4));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_dlmeta, c->h_dlmeta, 0));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_dl, hipEventDisableTiming));
+        c->dl_temp_nn = 0;
         const pg_lists D = pg_lists_carve(c->d_ad_off, R, K);
         c->d_ad_idx = D.ad_idx; c->d_par_off = D.par_off; c->d_par_idx = D.par_idx;
         c->d_heavy = D.heavy; c->d_chunk_beg = D.chunk_beg; c->d_chunk_cnt = D.chunk_cnt;
@@ -1737,6 +1756,110 @@ int phylo_sweep_node(phylo_ctx* c, int r, int k, double* out) {
     return PHYLO_OK;
 }
 
+// ---- the reverse pass's integer lists built on the device (phylo_revlists_dev.h): launches, then the few integers the host needs
+struct dl_meta {
+    std::vector<int32_t> ev_adp0, ev_slow0;
+    int32_t n_adp = 0, n_chunks = 0, n_slow = 0, n_par = 0;
+};
+static unsigned bit_length(size_t v) { unsigned b = 0; while (v) { ++b; v >>= 1; } return b ? b : 1; }
+extern "C++" {
+template <int ITEMS>
+static int dev_lists_adopters(phylo_ctx* c, const pg_dl_args& d, hipStream_t s) {
+    const size_t lds = pg_dl_sort<ITEMS>::storage_bytes + (size_t)d.K * 4;
+    static bool raised = false;                            // (beyond the 64 KB every kernel may ask for: say so once)
+    if (lds > 65536 && !raised) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)pg_dl_adopters<ITEMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
+    hipLaunchKernelGGL(pg_dl_adopters<ITEMS>, dim3(d.R), dim3(PG_DL_BLOCK), lds, s, d, bit_length((size_t)d.K));
+    return launch_check(c, "pg_dl_adopters");
+}
+}  // extern "C++"
+// Everything on sL; ev_dl is recorded when the lists that the coefficient chain and the host need are there (pg_dl_lists), the
+// parents' sort follows.  Nothing here waits for the host; dev_lists_wait does.
+static int dev_lists_launch(phylo_ctx* c, hipStream_t sL) {
+    const int N = c->N, K = c->K, R = N - 1;
+    const size_t nn = (size_t)R * K, nb = (nn + PG_DL_BLOCK - 1) / PG_DL_BLOCK;
+    const size_t meta_ints = (size_t)PG_DL_META_INTS(R);
+    void* ws = nullptr;
+    CHK(scratch_get(c, 8, (8 * nn + 4 * nb + meta_ints + 32) * 4, &ws));
+    pg_dl_args d{};
+    d.N = N; d.R = R; d.K = K;
+    d.anc = c->d_anc; d.child = c->d_child;
+    int32_t* w = (int32_t*)ws;
+    d.cnt_par = w; d.ticket = w + nn; w += nn + 16;
+    d.adopted = w; w += nn;
+    d.bsum = w; w += 4 * nb;
+    d.dmeta = w; w += meta_ints;
+    d.pkey = (uint32_t*)w; d.pval = (uint32_t*)w + 2 * nn; w += 4 * nn;
+    uint32_t* pkey_out = (uint32_t*)w;
+    d.L = pg_lists_carve(c->d_ad_off, (size_t)R, (size_t)K);
+    d.meta = c->hd_dlmeta;
+    const unsigned pbits = bit_length(2 * nn);
+    if (c->dl_temp_nn != nn) {                             // (the size query launches nothing)
+        size_t tp = 0;
+        HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tp, d.pkey, pkey_out, d.pval, (uint32_t*)d.L.par_idx, 2 * nn, 0u, pbits, sL));
+        c->dl_temp_p = tp; c->dl_temp_nn = nn;
+    }
+    void* tp = nullptr;
+    CHK(scratch_get(c, 9, c->dl_temp_p + 16, &tp));
+    if (K <= 1024) CHK(dev_lists_adopters<1>(c, d, sL));
+    else if (K <= 2048) CHK(dev_lists_adopters<2>(c, d, sL));
+    else if (K <= 4096) CHK(dev_lists_adopters<4>(c, d, sL));
+    else CHK(dev_lists_adopters<8>(c, d, sL));
+    if (R > 1) {
+        hipLaunchKernelGGL(pg_dl_count, dim3(cdiv((long)(2 * nn - 2 * (size_t)K), 256)), dim3(256), 0, sL, d);
+        CHK(launch_check(c, "pg_dl_count"));
+    }
+    hipLaunchKernelGGL(pg_dl_sums, dim3((unsigned)nb), dim3(PG_DL_BLOCK), 0, sL, d);
+    CHK(launch_check(c, "pg_dl_sums"));
+    hipLaunchKernelGGL(pg_dl_lists, dim3((unsigned)nb), dim3(PG_DL_BLOCK), 0, sL, d);
+    CHK(launch_check(c, "pg_dl_lists"));
+    HIPCHK(c, hipEventRecord(c->ev_dl, sL));
+    // the parents' sort: six small launches through rocPRIM's host code, 8 us of host time each -- captured once per shape (the
+    // buffers are the context's own and stay where they are), replayed with one call
+    const void* key[4] = {ws, tp, (const void*)c->d_ad_off, (const void*)nn};
+    if (c->dl_graph && memcmp(key, c->dl_graph_key, sizeof key) != 0) {
+        (void)hipGraphExecDestroy(c->dl_graph);
+        c->dl_graph = nullptr;
+    }
+    if (!c->dl_graph && !c->dl_no_graph) {
+        hipGraph_t gr = nullptr;
+        bool ok = hipStreamBeginCapture(sL, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            size_t bytes = c->dl_temp_p;
+            const hipError_t e1 = rocprim::radix_sort_pairs(tp, bytes, d.pkey, pkey_out, d.pval, (uint32_t*)d.L.par_idx, 2 * nn, 0u, pbits, sL);
+            const hipError_t e2 = hipStreamEndCapture(sL, &gr);
+            ok = e1 == hipSuccess && e2 == hipSuccess && gr && hipGraphInstantiate(&c->dl_graph, gr, nullptr, nullptr, 0) == hipSuccess;
+            if (gr) (void)hipGraphDestroy(gr);
+        }
+        if (!ok) {                                         // no capture on this runtime: the plain launches every time
+            (void)hipGetLastError();
+            c->dl_graph = nullptr;
+            c->dl_no_graph = true;
+        } else {
+            memcpy(c->dl_graph_key, key, sizeof key);
+        }
+    }
+    if (c->dl_graph) {
+        HIPCHK(c, hipGraphLaunch(c->dl_graph, sL));
+        } else {
+        size_t bytes = c->dl_temp_p;
+        HIPCHK(c, rocprim::radix_sort_pairs(tp, bytes, d.pkey, pkey_out, d.pval, (uint32_t*)d.L.par_idx, 2 * nn, 0u, pbits, sL));
+    }
+    return PHYLO_OK;
+}
+static int dev_lists_wait(phylo_ctx* c, dl_meta& m) {
+    CHK(wait_event_spin(c, c->ev_dl));
+    const int R = c->N - 1;
+    const int32_t* h = c->h_dlmeta;
+    m.ev_adp0.assign(h, h + R + 1);
+    m.ev_slow0.assign(h + R + 1, h + 2 * (R + 1));
+    const int32_t* t = h + 2 * (R + 1);
+    m.n_adp = t[0]; m.n_chunks = t[1]; m.n_slow = t[2]; m.n_par = t[3];
+    return PHYLO_OK;
+}
+
 static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q, phylo_stats* perf);
 
 int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q, phylo_stats* perf) {
@@ -1845,12 +1968,18 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
     //      ancestors and children in pinned host memory (asynchronous copies behind its last launch); the lists are built straight
     //      into the pinned image of the device slab (ad_off | ad_idx | par_off | par_idx | heavy | chunk_beg | chunk_cnt).
     CHK(wait_event_spin(c, c->ev_gcopy));
-    if (bg_free) {
+    auto launch_bg_free = [&]() -> int {
         HIPCHK(c, hipStreamWaitEvent(c->bgstream, c->ev_bgfork, 0));
         hipLaunchKernelGGL(pg_nodes_free, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, c->bgstream, g, 3);
         CHK(launch_check(c, "pg_nodes_free"));
         HIPCHK(c, hipEventRecord(c->ev_bgdone, c->bgstream));
-    }
+        return PHYLO_OK;
+    };
+    // After a lazy sweep with the plain proposal the lists are built by kernels (phylo_revlists_dev.h) and the host waits for a few
+    // dozen integers; PHYLO_REV_HOST_LISTS keeps the host builders (the A/B switch, and what every other form uses).
+    const bool dev_lists = early_free && !c->env.rev_host_lists && c->Kloc == K && K <= PG_DL_MAX_K;
+    dl_meta dm;
+    if (bg_free && !dev_lists) CHK(launch_bg_free());
     const auto host_t0 = std::chrono::steady_clock::now();
     const int64_t* anc = c->h_anc_p;
     const int32_t* child = c->h_child_p;
@@ -1861,7 +1990,7 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
     int32_t* const slow_flag = L.slow_flag;
     int32_t* const adp = L.adp;
     const size_t cap = L.cap;
-    pg_lists_clear(L, R, K);
+    if (!dev_lists) pg_lists_clear(L, R, K);
     std::vector<int32_t>& cur = c->h_cur;
     // Two chains of small dependent launches remain, both newest rank event first: the coefficients (on the context's stream) and
     // the adopted nodes' adjoints, which need the coefficients of their own and of later rank events only (ev_coeff[r]), on a
@@ -1873,8 +2002,23 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
     // (Measured, K = 2048: reverse pass 0.522 -> 0.476 ms with all 898 sites, 0.455 -> 0.466 with 256: large sweeps only, like the
     //  background launch.)
     const bool reorder = bg_free;
-    const bool two = !c->env.grad_one_stream && (c->env.grad_two_streams || nn >= 65536 || reorder);
+    const bool two = !c->env.grad_one_stream && (c->env.grad_two_streams || nn >= 65536 || reorder || dev_lists);
     hipStream_t sB = two ? c->gstream : c->stream;
+    // (the host has seen the sweep end: the second stream needs no event to start on its outputs, and the list kernels run
+    //  beside the early kernels)
+    if (dev_lists) {
+        CHK(dev_lists_launch(c, sB));
+        if (two) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dl, 0));   // the coefficient chain reads the adopters' lists
+        // the list kernels are workgroups of 1024 threads that everything else waits for: on a GPU that the background launch has
+        // filled they wait for a whole free CU each, kernel after kernel (lists ready after 120 us instead of 55): the background
+        // launch starts behind them.  (Measured, primate.p K = 2048 / DS1 K = 4096, reverse pass: background launch first 0.504 /
+        //  1.634 ms, behind the lists 0.486 / 1.653, behind the parents' sort 0.510 / 1.746; a high-priority second stream
+        //  changes nothing.)
+        if (bg_free) {
+            HIPCHK(c, hipStreamWaitEvent(c->bgstream, c->ev_dl, 0));
+            CHK(launch_bg_free());
+        }
+    }
     if (two) {
         HIPCHK(c, hipEventRecord(c->ev_gfork, c->stream));                 // everything launched so far (the early kernels)
         HIPCHK(c, hipStreamWaitEvent(sB, c->ev_gfork, 0));
@@ -1882,10 +2026,16 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
     std::vector<int32_t> rank_chunk0, ev_slow0;
     pg_parents_info pinfo{};
     size_t max_chunks = 0, n_chunks = 0;
-    if (early_free) pg_mark_adopted(R, K, anc, L);
+    if (early_free && !dev_lists) pg_mark_adopted(R, K, anc, L);
     auto parents_block = [&]() -> int {
-    // ---- parents, heavy nodes' chunks, flagged nodes by rank event (pg_build_parents)
-    pinfo = pg_build_parents(N, R, K, child, rows_form, early_free, L, cur, rank_chunk0, ev_slow0);
+    // ---- parents, heavy nodes' chunks, flagged nodes by rank event (pg_build_parents, or what pg_dl_lists reports)
+    if (dev_lists) {
+        CHK(dev_lists_wait(c, dm));
+        ev_slow0 = dm.ev_slow0;
+        pinfo.n_chunks = (size_t)dm.n_chunks; pinfo.max_chunks = 0; pinfo.n_slow = dm.n_slow; pinfo.n_par = dm.n_par;
+    } else {
+        pinfo = pg_build_parents(N, R, K, child, rows_form, early_free, L, cur, rank_chunk0, ev_slow0);
+    }
     max_chunks = pinfo.max_chunks; n_chunks = pinfo.n_chunks;
     {
         const int32_t ns = pinfo.n_slow;
@@ -1907,7 +2057,7 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
             g.slowpart = (double*)sp;
         }
     }
-    {   // what was used of everything between the adopters' lists and the adopted particles, by a kernel (pg_copy_words)
+    if (!dev_lists) {   // what was used of everything between the adopters' lists and the adopted particles, by a kernel (pg_copy_words)
         pg_copy3 cp{};
         const size_t o0 = (size_t)(par_off - ad_off), o1 = (size_t)(heavy - ad_off), o2 = (size_t)(slow_flag - ad_off);
         cp.src[0] = c->hd_csr + o0; cp.dst[0] = (uint32_t*)(c->d_ad_off + o0); cp.n[0] = nn + 1 + (size_t)par_off[nn];   // par_off | par_idx
@@ -1933,29 +2083,37 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
     }
         return PHYLO_OK;
     };
-    if (reorder) CHK(parents_block());
+    if (reorder || dev_lists) CHK(parents_block());
     std::vector<int32_t> ev_adp0;                          // adopted particles of rank event r: adp[ev_adp0[r] .. ev_adp0[r + 1])
-    const int32_t n_adp = pg_build_adopters(R, K, anc, L, cur, ev_adp0);
+    int32_t n_adp = 0;
+    if (dev_lists) { ev_adp0 = dm.ev_adp0; n_adp = dm.n_adp; }
+    else n_adp = pg_build_adopters(R, K, anc, L, cur, ev_adp0);
     // the adopters' lists are all the coefficient chain needs: it runs while the host goes on with the parents' lists.  When the
     // early pg_nodes_free has dealt with everybody nobody adopted, the chain runs over the adopted particles alone.
     const size_t ad_ints = (size_t)R * (K + 1) + nn;
-    HIPCHK(c, hipMemcpyAsync(c->d_ad_off, c->h_csr_p, ad_ints * 4, hipMemcpyHostToDevice, c->stream));
+    // With the parents' lists already there, the two chains are launched in turn, a rank event of each: the host needs ~3 us per
+    // call, and the adopted nodes' chain queued behind all the coefficient launches would start ~70 us late.
+    const bool interleave = early_free && two && (reorder || dev_lists);
+    auto launch_coeff = [&](int r) -> int {
+        const int na = ev_adp0[r + 1] - ev_adp0[r];
+        if (na > 0) {
+            hipLaunchKernelGGL(pg_coeff, dim3(na, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r, (int)ev_adp0[r]);
+            CHK(launch_check(c, "pg_coeff"));
+        }
+        if (two) HIPCHK(c, hipEventRecord(c->ev_coeff[r], c->stream));
+        return PHYLO_OK;
+    };
+    if (!dev_lists) HIPCHK(c, hipMemcpyAsync(c->d_ad_off, c->h_csr_p, ad_ints * 4, hipMemcpyHostToDevice, c->stream));
     if (early_free) {
-        HIPCHK(c, hipMemcpyAsync(c->d_adp, adp, (size_t)(n_adp ? n_adp : 1) * 4, hipMemcpyHostToDevice, c->stream));
+        if (!dev_lists) HIPCHK(c, hipMemcpyAsync(c->d_adp, adp, (size_t)(n_adp ? n_adp : 1) * 4, hipMemcpyHostToDevice, c->stream));
         g.adp = c->d_adp;
         if (n_adp > 0) {
             hipLaunchKernelGGL(pg_G, dim3(n_adp), dim3(64), 0, c->stream, g);
             CHK(launch_check(c, "pg_G"));
         }
         if (two) HIPCHK(c, hipEventRecord(c->ev_coeff[R - 1], c->stream));   // (the last rank event has no adopters: C is there)
-        for (int r = R - 2; r >= 0; --r) {
-            const int na = ev_adp0[r + 1] - ev_adp0[r];
-            if (na > 0) {
-                hipLaunchKernelGGL(pg_coeff, dim3(na, cdiv(N - r - 1, 4)), dim3(256), 0, c->stream, g, r, (int)ev_adp0[r]);
-                CHK(launch_check(c, "pg_coeff"));
-            }
-            if (two) HIPCHK(c, hipEventRecord(c->ev_coeff[r], c->stream));
-        }
+        if (!interleave)
+            for (int r = R - 2; r >= 0; --r) CHK(launch_coeff(r));
     } else {
         hipLaunchKernelGGL(pg_G, dim3(R * K), dim3(64), 0, c->stream, g);
         CHK(launch_check(c, "pg_G"));
@@ -1965,8 +2123,10 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
             if (two) HIPCHK(c, hipEventRecord(c->ev_coeff[r], c->stream));
         }
     }
-    hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
-    CHK(launch_check(c, "pg_leafterm"));
+    if (!interleave) {
+        hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
+        CHK(launch_check(c, "pg_leafterm"));
+    }
     // twisted proposal: the look-ahead merges of rank event r touch every internal node among the adopted roots.  Entries
     // (adopter, slot) grouped by node (ascending adopter), cut into chunks of PG_XCH; lists for all rank events in one upload.
     std::vector<int32_t> ev_chunk0((size_t)R + 1, 0), ev_node0((size_t)R + 1, 0);
@@ -2050,7 +2210,7 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         HIPCHK(c, hipMemcpyAsync(d_xlists, pk.data(), pk.size() * 4, hipMemcpyHostToDevice, sB));
         CHK(scratch_get(c, 7, tw_max_chunks * (size_t)S * 4 * 8, &d_tpart));
     }
-    if (!reorder) CHK(parents_block());
+    if (!reorder && !dev_lists) CHK(parents_block());
     const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     if (twist) {
         const int32_t* xl = (const int32_t*)d_xlists;
@@ -2072,6 +2232,7 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         CHK(launch_check(c, "pg_nodes_free"));
     }
     for (int r = R - 1; r >= 0; --r) {
+        if (interleave && r >= 1) CHK(launch_coeff(r - 1));
         if (two) HIPCHK(c, hipStreamWaitEvent(sB, c->ev_coeff[r], 0));
         if (twist && ev_chunk0[r + 1] > ev_chunk0[r]) {
             hipLaunchKernelGGL(pg_twist_xchunks, dim3(ev_chunk0[r + 1] - ev_chunk0[r], cdiv(S, 256)), dim3(256), 0, sB, g, r, (int)ev_chunk0[r]);
@@ -2089,7 +2250,8 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         if (rows_form) {
             const int nslow = ev_slow0[r + 1] - ev_slow0[r];
             if (nslow > 0) {
-                hipLaunchKernelGGL(pg_nodes_rows, dim3(nslow, g.TS), dim3(256), 0, sB, g, r, (int)ev_slow0[r], early_free ? (int)rank_chunk0[r] : 0);
+                hipLaunchKernelGGL(pg_nodes_rows, dim3(nslow, g.TS), dim3(256), 0, sB, g, r, (int)ev_slow0[r],
+                                   early_free && !dev_lists ? (int)rank_chunk0[r] : 0);   // (device-built lists: heavy[] is the global chunk index)
                 ++node_launches;
             }
         } else {
@@ -2097,6 +2259,10 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
             ++node_launches;
         }
         CHK(launch_check(c, "pg_nodes"));
+    }
+    if (interleave) {
+        hipLaunchKernelGGL(pg_leafterm, dim3(cdiv(K, 256)), dim3(256), 0, c->stream, g);
+        CHK(launch_check(c, "pg_leafterm"));
     }
     if (two) {
         HIPCHK(c, hipEventRecord(c->ev_gjoin, sB));
@@ -2125,8 +2291,8 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         *perf = c->stats;
         perf->sweep_ms = ms;
         perf->n_launches = R + 7 + node_launches + tw_launches;
-        perf->merge_ms = host_ms;                          // here: host time of the integer lists (the GPU runs the early kernels meanwhile)
-        perf->merge_launches = 0;
+        perf->merge_ms = host_ms;                          // here: host time of the integer lists (built, or waited for: device lists)
+        perf->merge_launches = dev_lists ? 1 : 0;          // here: 1 = the lists were built by kernels (phylo_revlists_dev.h)
     }
     return PHYLO_OK;
 }
@@ -2164,6 +2330,57 @@ int phylo_debug_reverse_lists(int N, int K, const int64_t* ancestors, const int3
         meta[6 + r] = ev_adp0[r];
         meta[6 + (R + 1) + r] = rank_chunk0[r];
         meta[6 + 2 * (R + 1) + r] = ev_slow0[r];
+    }
+    return PHYLO_OK;
+}
+
+static int debug_device_lists_run(phylo_ctx* c, int32_t* lists, int64_t n_lists, int32_t* meta, int n_meta);
+
+int phylo_debug_device_lists_of(phylo_ctx* c, const int64_t* ancestors, const int32_t* child, int32_t* lists, int64_t n_lists,
+                                int32_t* meta, int n_meta) {
+    CHK(bind(c));
+    if (c->Kloc != c->K || c->K > PG_DL_MAX_K || !child || (c->N > 2 && !ancestors))
+        return fail(c, PHYLO_EINVAL, "phylo_debug_device_lists_of: not sharded, K <= %d, ancestors and child given", PG_DL_MAX_K);
+    CHK(ensure_sweep_state(c));
+    CHK(ensure_graph_state(c));
+    const int R = c->N - 1, K = c->K;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->swept = false;                                      // the sweep's genealogy is overwritten: no reverse pass on it after this
+    c->last_graph = false;
+    if (R > 1) HIPCHK(c, hipMemcpy(c->d_anc, ancestors, (size_t)(R - 1) * K * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_child, child, (size_t)R * K * 2 * 4, hipMemcpyHostToDevice));
+    return debug_device_lists_run(c, lists, n_lists, meta, n_meta);
+}
+
+int phylo_debug_device_lists(phylo_ctx* c, int32_t* lists, int64_t n_lists, int32_t* meta, int n_meta, int64_t* ancestors, int32_t* child) {
+    CHK(bind(c));
+    if (!c->swept || !c->last_graph || !c->last_graph_marks || c->last_graph_twist || c->Kloc != c->K || c->K > PG_DL_MAX_K)
+        return fail(c, PHYLO_ESTATE, "phylo_debug_device_lists needs a preceding lazy sweep with PHYLO_KEEP_GRAPH and the plain proposal, not sharded, K <= %d", PG_DL_MAX_K);
+    const int R = c->N - 1, K = c->K;
+    CHK(debug_device_lists_run(c, lists, n_lists, meta, n_meta));
+    if (ancestors && R > 1) memcpy(ancestors, c->h_anc_p, (size_t)(R - 1) * K * 8);   // the pinned copies the sweep left
+    if (child) memcpy(child, c->h_child_p, (size_t)R * K * 2 * 4);
+    return PHYLO_OK;
+}
+
+static int debug_device_lists_run(phylo_ctx* c, int32_t* lists, int64_t n_lists, int32_t* meta, int n_meta) {
+    const int R = c->N - 1, K = c->K;
+    const size_t ints = pg_lists_ints((size_t)R, (size_t)K);
+    if (!lists || !meta || n_lists < (int64_t)ints || n_meta < 6 + 3 * (R + 1))
+        return fail(c, PHYLO_EINVAL, "phylo_debug_device_lists: lists needs %zu ints, meta %d", ints, 6 + 3 * (R + 1));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_ad_off, 0xff, ints * 4, c->stream));        // (what the builders do not write stays -1)
+    CHK(dev_lists_launch(c, c->stream));
+    dl_meta m;
+    CHK(dev_lists_wait(c, m));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(lists, c->d_ad_off, ints * 4, hipMemcpyDeviceToHost));
+    meta[0] = m.n_adp; meta[1] = m.n_chunks; meta[2] = 0; meta[3] = m.n_slow; meta[4] = m.n_par;
+    meta[5] = (int32_t)pg_lists_cap((size_t)R, (size_t)K);
+    for (int r = 0; r <= R; ++r) {
+        meta[6 + r] = m.ev_adp0[r];
+        meta[6 + (R + 1) + r] = 0;
+        meta[6 + 2 * (R + 1) + r] = m.ev_slow0[r];
     }
     return PHYLO_OK;
 }

@@ -317,6 +317,128 @@ def test_gradient_same_on_two_streams(monkeypatch, twisted):
         assert np.array_equal(g1[key], g2[key]), key
 
 
+def _device_lists_match_host(N, S, K, genome, Q, pi, ll, lr, seed):
+    """The lists the device kernels build (phylo_revlists_dev.h) against the host builders on the same graph: identical but for the
+    two documented differences -- heavy[] global instead of per rank event, a node's flagged parents ascending instead of descending."""
+    with _ffi.Context(K, N, S) as ctx:
+        ctx.set_leaves(genome)
+        ctx.set_model(Q, pi, ll, lr)
+        ctx.sweep(seed, _ffi.FLAGS_DEFAULT | _ffi.KEEP_GRAPH)
+        d = ctx.debug_device_lists()
+        d2 = ctx.debug_device_lists()
+    return _compare_device_lists_with_host(N, K, d, d2)
+
+
+def _compare_device_lists_with_host(N, K, d, d2):
+    h = _ffi.debug_reverse_lists(N, K, d['ancestors'], d['child'], early_free=True, rows_form=True)
+    R, nn = N - 1, (N - 1) * K
+    for key in ('n_adp', 'n_chunks', 'n_slow', 'n_par'):
+        assert d[key] == h[key], key
+    for key in ('ev_adp0', 'ev_slow0'):
+        assert np.array_equal(d[key], h[key]), key
+    assert np.array_equal(d['ad_off'][1:], h['ad_off'][1:])
+    assert np.array_equal(d['ad_idx'][1:], h['ad_idx'][1:])
+    assert np.array_equal(d['adp'][:h['n_adp']], h['adp'][:h['n_adp']])
+    assert np.array_equal(d['par_off'], h['par_off'])
+    assert np.array_equal(d['slow_flag'], h['slow_flag'])
+    assert np.array_equal(d['slow_idx'][:h['n_slow']], h['slow_idx'][:h['n_slow']])
+    assert np.array_equal(d['chunk_beg'][:h['n_chunks']], h['chunk_beg'][:h['n_chunks']])
+    assert np.array_equal(d['chunk_cnt'][:h['n_chunks']], h['chunk_cnt'][:h['n_chunks']])
+    rc0 = np.repeat(h['rank_chunk0'][:R], K)
+    assert np.array_equal(d['heavy'], np.where(h['heavy'] >= 0, h['heavy'] + rc0, -1))
+    FREE = 1 << 30
+    po = h['par_off']
+    n_two = 0
+    for x in np.nonzero(np.diff(po))[0]:                # a node's list: the free parents ascending, then the flagged ones
+        a, b = d['par_idx'][po[x]:po[x + 1]], h['par_idx'][po[x]:po[x + 1]]
+        fa, fb = a[(a & FREE) != 0], b[(b & FREE) != 0]
+        assert np.array_equal(fa, fb) and np.array_equal(a[:len(fa)], fa), x
+        assert np.array_equal(a[len(fa):], b[len(fb):][::-1]), x
+        assert np.all(np.diff(a[len(fa):]) > 0), x
+        n_two += len(a) - len(fa) >= 2
+    for key in ('ad_idx', 'par_idx', 'slow_idx', 'adp', 'heavy', 'chunk_beg'):   # built twice: the same lists
+        assert np.array_equal(d[key], d2[key]), key
+    return h, n_two
+
+
+def test_device_built_lists_equal_the_host_builders_degenerate_genealogy():
+    """Real sites: a few ancestors take nearly every draw (heavy nodes, chunks)."""
+    genome = load_dataset('primate_data')['genome'][:, :96]
+    N = genome.shape[0]
+    rng = np.random.default_rng(5)
+    Q, pi, ll, lr = _model(rng, N)
+    h, _ = _device_lists_match_host(N, 96, 1500, genome, Q, pi, ll, lr, seed=4)   # (K not a multiple of the builders' block)
+    assert h['n_chunks'] > 0
+
+
+def test_device_built_lists_equal_the_host_builders_flat_weights():
+    """All-gap rows: hundreds of distinct ancestors per rank event, nodes with several flagged parents."""
+    rng = np.random.default_rng(43)
+    N, S, K = 9, 40, 700
+    Q, pi, ll, lr = _model(rng, N)
+    h, n_two = _device_lists_match_host(N, S, K, np.ones((N, S, 4)), Q, pi, ll, lr, seed=3)
+    assert h['n_adp'] > K and n_two > 0
+
+
+@pytest.mark.parametrize("N,K,survivors,seed", [
+    (2, 1, 1, 0), (2, 5, 3, 1), (3, 4, 2, 2), (4, 3, 3, 3), (6, 64, 3, 4), (6, 64, 64, 5), (7, 130, 5, 6), (8, 257, 12, 7),
+    (12, 512, 4, 8), (5, 1023, 2, 9), (5, 1025, 40, 10), (4, 2100, 7, 11), (3, 4097, 300, 12), (3, 8192, 3, 13),
+])
+def test_device_built_lists_on_the_random_genealogies_of_the_cpu_tests(N, K, survivors, seed):
+    """The cases of tests/test_revlists_cpu.py (random genealogies from flat to degenerate, children from any earlier rank event),
+    and more particles than they use -- every workgroup shape of pg_dl_adopters (1, 2, 4, 8 adopters per thread), K not a multiple
+    of anything -- through the device builders, against the host builders those tests check against a restatement in Python."""
+    from test_revlists_cpu import _random_genealogy          # (pytest puts tests/ on sys.path)
+    rng = np.random.default_rng(seed)
+    anc, child = _random_genealogy(rng, N, K, survivors) if K <= 1100 else _fast_genealogy(rng, N, K, survivors)
+    with _ffi.Context(K, N, 4) as ctx:
+        d = ctx.debug_device_lists(anc, child)
+        d2 = ctx.debug_device_lists(anc, child)
+        with pytest.raises(_ffi.PhyloError):             # the genealogy replaced the sweep's: no reverse pass on it
+            ctx.sweep_backward()
+    _compare_device_lists_with_host(N, K, d, d2)
+
+
+def _fast_genealogy(rng, N, K, survivors):
+    """_random_genealogy of tests/test_revlists_cpu.py without its Python loops over particles (large K)."""
+    R = N - 1
+    anc = np.zeros((max(R - 1, 0), K), dtype=np.int64)
+    for r in range(R - 1):
+        pool = rng.choice(K, size=min(survivors, K), replace=False)
+        anc[r] = rng.choice(pool, size=K, p=rng.dirichlet(np.full(len(pool), 0.3)))
+    child = rng.integers(0, N, size=(R, K, 2)).astype(np.int32)
+    for r in range(1, R):
+        internal = rng.random((K, 2)) < 0.5
+        rp = rng.integers(0, r, size=(K, 2))
+        own = rng.random((K, 2)) < 0.8
+        kp = np.where(own & (rp < R - 1), anc[np.minimum(rp, max(R - 2, 0)), np.arange(K)[:, None]] if R > 1 else 0, rng.integers(0, K, size=(K, 2)))
+        child[r] = np.where(internal, N + rp * K + kp, child[r])
+    return anc, child
+
+
+@pytest.mark.parametrize("N,S,K", [(2, 5, 4), (3, 7, 2), (4, 65, 3)])
+def test_device_built_lists_edge_shapes(N, S, K):
+    rng = np.random.default_rng(100 + N * 10 + K)
+    Q, pi, ll, lr = _model(rng, N)
+    _device_lists_match_host(N, S, K, _codes_genome(rng, N, S), Q, pi, ll, lr, seed=6)
+
+
+def test_gradient_same_with_host_built_lists(monkeypatch):
+    """PHYLO_REV_HOST_LISTS keeps the host builders: the same gradient to the last few bits (flagged parents are added in another
+    fixed order), on a degenerate and on a flat genealogy."""
+    rng = np.random.default_rng(46)
+    N, S, K = 8, 130, 300
+    Q, pi, ll, lr = _model(rng, N)
+    for genome in (_codes_genome(rng, N, S), np.ones((N, S, 4))):
+        g_dev = _check(genome, Q, pi, ll, lr, K=K, seed=8)[0]
+        monkeypatch.setenv('PHYLO_REV_HOST_LISTS', '1')
+        g_host = _check(genome, Q, pi, ll, lr, K=K, seed=8)[0]
+        monkeypatch.delenv('PHYLO_REV_HOST_LISTS')
+        for key in ('d_lam_l', 'd_lam_r', 'd_pi', 'd_Q'):
+            scale = max(np.max(np.abs(g_host[key])), 1e-300)
+            assert np.max(np.abs(g_dev[key] - g_host[key])) / scale < 1e-12, key
+
+
 def test_gradient_flat_weights_many_adopted_nodes():
     """All-gap rows: every weight equal, so hundreds of distinct ancestors survive each resampling -- many adopted nodes with few
     parents each (the opposite of the degenerate genealogies of real data)."""
