@@ -52,6 +52,29 @@ def chain_rules(v, Q, pi_1xA, lam_l, lam_r, raw):
     return g
 
 
+def mean_of_samples(samples, ctx=None):
+    """Mean of (logZ, grads) over independent particle systems: the samples of this process, and with ctx (a context that has
+    joined the ranks' communicator) those of every rank -- one host all-gather of the ~45 numbers per sample, summed in (rank,
+    sample) order on every rank: the same bits everywhere, so the ranks' variables never drift apart, and the same bits as one
+    process taking all the samples itself."""
+    names = sorted(samples[0][1])
+    rows = np.stack([np.concatenate([[float(z)]] + [np.asarray(g[n], dtype=np.float64).reshape(-1) for n in names]) for z, g in samples])
+    if ctx is not None:
+        rows = ctx.comm_allgather_blob(rows)
+        rows = rows.reshape(-1, rows.shape[-1])
+    tot = rows[0].copy()
+    for r in range(1, rows.shape[0]):
+        tot = tot + rows[r]
+    tot = tot / rows.shape[0]
+    out, o = {}, 1
+    for n in names:
+        shape = np.shape(samples[0][1][n])
+        size = int(np.prod(shape)) if shape else 1
+        out[n] = tot[o:o + size].reshape(shape)
+        o += size
+    return float(tot[0]), out
+
+
 class GradientDescent:
     """tf.train.GradientDescentOptimizer(lr).minimize(cost): var <- var - lr d cost/d var, cost = -logZ."""
 
@@ -128,9 +151,18 @@ class Trainer:
         raw['forward_ms'] = out['stats']['sweep_ms']
         return out['logZ'], chain_rules(self.v, Q, pi, lam_l, lam_r, raw), raw
 
-    def step(self, sites, seed):
-        """_, cost = sess.run([self.optimizer, self.cost], feed_dict={self.core: data_batch})  (vcsmc.py:534)."""
+    def step(self, sites, seed, more_seeds=(), comm_ctx=None):
+        """_, cost = sess.run([self.optimizer, self.cost], feed_dict={self.core: data_batch})  (vcsmc.py:534).
+        Data-parallel training: more_seeds = further independent particle systems swept by this process for the same step,
+        comm_ctx = a context that has joined the ranks (every rank sweeps its own systems with its own seeds); the optimiser takes
+        ONE step on the mean gradient of all of them (mean_of_samples), the same step on every rank."""
         logZ, grads, raw = self.gradients(sites, seed)
+        if more_seeds or comm_ctx is not None:
+            samples = [(logZ, grads)]
+            for s2 in more_seeds:
+                z2, g2, raw = self.gradients(sites, s2)
+                samples.append((z2, g2))
+            logZ, grads = mean_of_samples(samples, comm_ctx)
         self.opt.apply(self.v, grads)
         self.last = {'logZ': logZ, 'grads': grads, 'raw': raw}
         return -logZ

@@ -318,8 +318,14 @@ class VCSMC:
         print((self.K, self.N, self.S, self.A))
         print('==========================================================')
         ctx = self._context()                              # fixes the device (and joins the ranks when --n_gpus > 1)
-        if getattr(self, '_world', 1) > 1:
-            # every rank takes the optimiser steps redundantly, so all of them must train on the SAME site minibatches; python's
+        world, rank = getattr(self, '_world', 1), getattr(self, '_rank', 0)
+        # --train_parallel replicas (the default with --n_gpus > 1): data-parallel training -- on every minibatch each rank sweeps
+        # its OWN K-particle system(s) (own seeds) on its own GPU and the optimiser steps on the mean of all gradients, i.e.
+        # world x grad_samples independent ELBO samples per step.  redundant: every rank takes the identical step.
+        replicas = world > 1 and str(getattr(self.args, 'train_parallel', 'replicas') or 'replicas') == 'replicas'
+        n_local = max(1, int(getattr(self.args, 'grad_samples', 1) or 1))   # particle systems per step and rank
+        if world > 1:
+            # all ranks must train on the SAME site minibatches; python's
             # global RNG (unseeded, like the reference) differs from process to process: rank 0's slices are everybody's
             flat = ctx.comm_allgather_blob(np.asarray(sum(slices, []), dtype=np.int32))[0]
             cuts = np.cumsum([len(sl) for sl in slices])[:-1]
@@ -347,7 +353,11 @@ class VCSMC:
                     for j in range(len(slices) - 1):                       # vcsmc.py:533 (the last slice is never used)
                         seed = self.seed + self._sweeps
                         self._sweeps += 1
-                        self.minibatch_costs.append(trainer.step(slices[j], seed))
+                        # sample i of the step (i = rank * grad_samples + g when the ranks train as replicas) draws from seed + i 2^32:
+                        # seeds are 64-bit, so 2 ranks x 1 sample and 1 rank x 2 samples are the same training run bit for bit
+                        first = rank * n_local if replicas else 0
+                        seeds = [seed + ((first + g) << 32) for g in range(n_local)]
+                        self.minibatch_costs.append(trainer.step(slices[j], seeds[0], seeds[1:], ctx if replicas else None))
                     self._sync_from_variables()
                 elbo = self.sample_phylogenies()
                 best_k = int(np.argmax(self.log_likelihood_R))

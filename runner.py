@@ -3,8 +3,8 @@
 
 Same flags and defaults.  Differences: datasets come from an explicit table
 (phylo_amd/datasets.py) instead of `exec(args.dataset + ' = True')`; `--twisting` is accepted as an alias of
-`--nested` (the reference's README advertises it, its parser lacks it); `--seed`, `--n_gpus` and `--ambiguity`
-(default: the reference's KeyError on characters such as DS7's 'N'; `iupac` encodes them) are new.
+`--nested` (the reference's README advertises it, its parser lacks it); `--seed`, `--n_gpus`, `--train_parallel`,
+`--grad_samples` and `--ambiguity` (default: the reference's KeyError on characters such as DS7's 'N'; `iupac` encodes them) are new.
 """
 import argparse
 
@@ -31,7 +31,14 @@ def parse_args(argv=None):
     parser.add_argument('--n_gpus', type=int, default=1,
                         help='one process per GPU (python -m torch.distributed.run --nproc-per-node N runner.py --n_gpus N ...): the '
                              'particles of the EVALUATION sweeps are sharded over the ranks (global resampling, same bits as one GPU); '
-                             'the optimiser steps are not sharded: every rank takes the same step on its own device')
+                             'training: see --train_parallel')
+    parser.add_argument('--train_parallel', choices=('replicas', 'redundant'), default='replicas',
+                        help='with --n_gpus N > 1: replicas = data-parallel training, every rank sweeps its own n_particles-particle '
+                             'system per minibatch (own seed) and the optimiser steps on the mean gradient of the N ranks; '
+                             'redundant = every rank takes the identical step (equals the one-process run bit for bit)')
+    parser.add_argument('--grad_samples', type=int, default=1,
+                        help='independent particle systems swept per optimiser step (and per rank with --train_parallel replicas); the '
+                             'step is taken on their mean gradient')
     parser.add_argument('--ambiguity', choices=('error', 'iupac'), default='error',
                         help="characters outside the dataset's alphabet: KeyError like the reference, or IUPAC indicator rows")
     args = parser.parse_args(argv)

@@ -254,11 +254,52 @@ def test_comm_init_rejects_bad_world():
     ctx.close()
 
 
-def test_runner_n_gpus_equals_single_process():
-    """`runner.py --n_gpus 2` (two processes on GPU 0, hostshm): the particles are sharded for the evaluation sweeps,
-    every rank takes the same optimiser steps, and ELBOs, parameters and trees equal the one-process run."""
+def _run_runner(world, argv, port_salt):
+    with tempfile.TemporaryDirectory() as tmp:
+        env = dict(os.environ, PHYLO_RDZV_DIR=tmp, MASTER_PORT=str(29100 + os.getpid() % 800 + port_salt), PHYLO_COMM='hostshm')
+        procs = []
+        for r in range(world):
+            out = os.path.join(tmp, "w%d.npz" % r)
+            cmd = [sys.executable, os.path.join(ROOT, "tests", "_runner_worker.py"), str(r), str(world), out, '--'] + argv + \
+                  ['--n_gpus', str(world)]
+            procs.append((out, subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        res = []
+        for out, p in procs:
+            log, _ = p.communicate(timeout=240)
+            assert p.returncode == 0, log.decode()[-2000:]
+            res.append(dict(np.load(out)))
+        return res
+
+
+def test_runner_replicas_train_data_parallel():
+    """`runner.py --n_gpus 2` in its default training mode (--train_parallel replicas; two processes on GPU 0, hostshm): every
+    rank sweeps its own particle system per minibatch, the optimiser steps on the mean gradient -- both ranks end with the same
+    bits, and they are the bits of ONE process that takes both samples itself (--grad_samples 2); the steps differ from a
+    one-sample run's."""
     argv = ['--dataset', 'primate_data_wang', '--n_particles', '32', '--num_epoch', '2', '--batch_size', '256',
             '--optimizer', 'Adam', '--learning_rate', '0.05', '--seed', '4']
+    two = _run_runner(2, argv, 11)
+    one2 = _run_runner(1, argv + ['--grad_samples', '2'], 12)[0]
+    one1 = _run_runner(1, argv, 13)[0]
+    for r in two:
+        assert np.array_equal(r['elbos'], one2['elbos'])
+        assert np.array_equal(r['lam'].view(np.uint64), one2['lam'].view(np.uint64))
+        assert np.array_equal(r['log_weights'].view(np.uint64), one2['log_weights'].view(np.uint64))
+        np.testing.assert_array_equal(r['ancestors'], one2['ancestors'])
+    assert not np.array_equal(one1['lam'], one2['lam'])
+    # 2 ranks x 2 samples = 1 rank x 4 samples
+    four = _run_runner(2, argv + ['--grad_samples', '2'], 14)
+    one4 = _run_runner(1, argv + ['--grad_samples', '4'], 15)[0]
+    for r in four:
+        assert np.array_equal(r['lam'].view(np.uint64), one4['lam'].view(np.uint64))
+        assert np.array_equal(r['elbos'], one4['elbos'])
+
+
+def test_runner_n_gpus_equals_single_process():
+    """`runner.py --n_gpus 2 --train_parallel redundant` (two processes on GPU 0, hostshm): the particles are sharded for the
+    evaluation sweeps, every rank takes the same optimiser steps, and ELBOs, parameters and trees equal the one-process run."""
+    argv = ['--dataset', 'primate_data_wang', '--n_particles', '32', '--num_epoch', '2', '--batch_size', '256',
+            '--optimizer', 'Adam', '--learning_rate', '0.05', '--seed', '4', '--train_parallel', 'redundant']
     outs = {}
     for world in (1, 2):
         with tempfile.TemporaryDirectory() as tmp:

@@ -138,3 +138,69 @@ def test_sharded_protocol_world2(K, seed, local_tables, lazy, flags):
         mp.spawn(_worker, args=(2, port, K, seed, tmp, local_tables, lazy, flags), nprocs=2, join=True)
         fetched = sum(int(np.load(os.path.join(tmp, 'fetch%d.npy' % r))[0]) for r in range(2))
         assert fetched > 0, "the test never exercised a remote child"
+
+
+def _train_worker(rank, world, port, tmp, steps):
+    """Data-parallel training on CPU: the gradient of each rank's own particle system from the gradient oracle, the product's
+    mean over ranks (phylo_amd/train.py: mean_of_samples) with the all-gather over gloo, the product's Adam."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import cpu_grad as G
+    from phylo_amd import train as T
+    from phylo_amd.datasets import load_dataset
+
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    class Ctx:
+        def comm_allgather_blob(self, a):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            return np.stack([o.numpy() for o in out])
+
+    g = load_dataset('primate_data_wang')['genome'][:5, :40]
+    N, K = g.shape[0], 8
+    v = T.Variables(N, np.log(10.0), False)
+    opt = T.make_optimizer('Adam', 0.05)
+    for step in range(steps):
+        Q, pi, ll, lr = v.evaluate()
+        raw = G.sweep_grad(g, Q, pi, ll, lr, K, 100 + step + (rank << 32), 0)
+        grads = T.chain_rules(v, Q, pi, ll, lr, raw)
+        logZ, grads = T.mean_of_samples([(raw['logZ'], grads)], Ctx())
+        opt.apply(v, grads)
+    np.savez(os.path.join(tmp, 'v%d.npz' % rank), **{n: getattr(v, n) for n in v.names()}, logZ=logZ)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_world2_equals_one_process_with_two_samples():
+    """Two ranks, one particle system each per step == one process, two systems per step: same variables bit for bit after three
+    Adam steps, and both ranks hold the same bits."""
+    import torch.multiprocessing as mp
+    from oracle import cpu_grad as G
+    from phylo_amd import train as T
+    from phylo_amd.datasets import load_dataset
+    steps = 3
+    port = 29500 + (os.getpid() * 11 + 77) % 1000
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_train_worker, args=(2, port, tmp, steps), nprocs=2, join=True)
+        got = [dict(np.load(os.path.join(tmp, 'v%d.npz' % r))) for r in range(2)]
+    g = load_dataset('primate_data_wang')['genome'][:5, :40]
+    N, K = g.shape[0], 8
+    v = T.Variables(N, np.log(10.0), False)
+    opt = T.make_optimizer('Adam', 0.05)
+    for step in range(steps):
+        Q, pi, ll, lr = v.evaluate()
+        samples = []
+        for i in range(2):
+            raw = G.sweep_grad(g, Q, pi, ll, lr, K, 100 + step + (i << 32), 0)
+            samples.append((raw['logZ'], T.chain_rules(v, Q, pi, ll, lr, raw)))
+        logZ, grads = T.mean_of_samples(samples)
+        opt.apply(v, grads)
+    for n in v.names():
+        for r in range(2):
+            assert np.array_equal(np.asarray(getattr(v, n)).view(np.uint64), got[r][n].view(np.uint64)), (n, r)
+    assert float(got[0]['logZ']) == float(got[1]['logZ']) == logZ
