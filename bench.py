@@ -43,7 +43,7 @@ import numpy as np  # noqa: E402
 from phylo_amd import _ffi  # noqa: E402
 from phylo_amd import model as M  # noqa: E402
 from phylo_amd.datasets import load_dataset, synthetic_alignment  # noqa: E402
-from phylo_amd.rendezvous import exchange_comm_id  # noqa: E402
+from phylo_amd.rendezvous import FileSync, exchange_comm_id  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 N_SIMD = 256 * 4           # 256 CUs x 4 SIMD-32 (MI355X_MICROARCH.md)
@@ -177,7 +177,11 @@ def main():
     if a.params:
         pz = np.load(a.params)
         Q, pi, lam, lam_r = pz['Q'], pz['pi'], pz['lam_l'], pz['lam_r']
-    K_global = a.n_particles * world
+    K_global = a.n_particles * world                  # particles of one sweep (sharded over the ranks)
+    # N > 1, last resort and comparison figure: every rank runs its OWN sweeps of --n_particles particles, no exchange at all
+    # (PHYLO_BENCH_INDEPENDENT=1 forces it).  The ranks then meet through files (no communicator needed).
+    fs = FileSync(rank, world) if world > 1 else None
+    independent = False
 
     ndev = _ffi.device_count()
     if ndev < 1:
@@ -197,10 +201,13 @@ def main():
     sharded = world > 1 or bool(os.environ.get('PHYLO_COMM_FORCE_RCCL'))   # the env: rehearse the sharded loop on one rank
     sweep_flags = _ffi.FLAGS_DEFAULT | (_ffi.TWISTING if a.twisting else 0) | (_ffi.EAGER_NODES if a.eager else 0)
 
+    live = []                                             # every context alive, in creation order (closed in reverse: sharers first)
+
     def make_contexts():
         ctxs = []
         for i in range(n_streams):
             c = _ffi.Context(K_global * batch, N, S, device=local_rank % ndev)
+            live.append(c)
             c.set_leaves(g)
             c.set_model(Q, pi, lam, lam_r, jc69_closed_form=a.jcmodel)
             ctxs.append(c)
@@ -212,18 +219,36 @@ def main():
         single = ctxs[0]
         if batch > 1:                                     # one K-particle context: remainder sweeps, single-sweep latency
             single = _ffi.Context(K_global, N, S, device=local_rank % ndev)
+            live.append(single)
             single.set_leaves(g)
             single.set_model(Q, pi, lam, lam_r, jc69_closed_form=a.jcmodel)
             if sharded:
                 single.comm_share(ctxs[0])
         return ctxs, single
 
-    ctxs, single = make_contexts()
-    ctx = ctxs[0]
-    first_contact = {"exchange": ctx.comm_exchange_kind(), "fallback": None}
+    def close_all():
+        while live:
+            try:
+                live.pop().close()
+            except Exception:
+                pass
+
+    def barrier():
+        if independent:
+            fs.barrier()
+        else:
+            ctx.comm_barrier()
+
+    def gmax(x):
+        return fs.max(x) if independent else ctx.comm_max(x)
+
+    ctxs, single, ctx = [], None, None
+    first_contact = {"exchange": None, "fallback": None}
 
     def run(n, seed0):
         nb = n // batch
+        if independent:
+            seed0 += rank * 1000003                       # every rank its own sweeps
         if sharded:
             # the contexts in flight advance rank event by rank event, so every rank issues the collectives of the shared
             # communicator in the same order; each context carries `batch` independent sweeps (its K = batch * K_global
@@ -261,40 +286,60 @@ def main():
         for c in ctxs:
             c.synchronize()
 
-    # untimed: every context (and its pool's pages) touched once.  First contact with real links (N > 1): if the device-side exchange
-    # fails on any rank (a flag wait timed out: phylo_sweep_fetch reports it) every rank rebuilds its contexts on the collective
-    # path (PHYLO_P2P=0) and the line says so, instead of ending the run without a number
-    failed, why = 0.0, None
-    try:
-        run(n_streams * batch, a.seed + 2000)
-        for c in ctxs:
-            c.sweep_fetch(arrays=False)
-    except _ffi.PhyloError as e:
-        failed, why = 1.0, str(e)
-    if world > 1 and ctx.comm_max(failed) > 0.0:
-        if first_contact["exchange"] != 'p2p':
-            raise SystemExit("rank %d: the sharded sweep failed on the collective path: %s" % (rank, why))
-        if single is not ctx:
-            single.close()
-        for c in reversed(ctxs):
-            c.close()
-        os.environ['PHYLO_P2P'] = '0'
-        ctxs, single = make_contexts()
-        ctx = ctxs[0]
-        first_contact = {"exchange": ctx.comm_exchange_kind(), "fallback": "device-side exchange failed on some rank (%s): collective path" % (why or "a peer")}
-        run(n_streams * batch, a.seed + 2000)
-    elif failed:
-        raise SystemExit(why)
+    # untimed: contexts built, every context (and its pool's pages) touched once.  First contact with real links (N > 1): if a form
+    # fails on ANY rank (the ranks agree through files, not through the communicator that may be what failed) every rank drops its
+    # contexts and tries the next form -- the device-side exchange, then the collective path (PHYLO_P2P=0), then independent sweeps
+    # per rank -- and the line says what happened, instead of ending the run without a number.
+    forms = ['default'] if world == 1 else (['independent'] if os.environ.get('PHYLO_BENCH_INDEPENDENT') else ['default', 'collective', 'independent'])
+    forced_fail = [f for f in os.environ.get('PHYLO_BENCH_FAIL', '').split(',') if f]       # (tests: make a form fail on purpose)
+    tried = []
+    for form in forms:
+        if form == 'collective':
+            if first_contact["exchange"] not in ('p2p', None):
+                continue                                  # the first form already was the collective path
+            os.environ['PHYLO_P2P'] = '0'
+        if form == 'independent':
+            independent, sharded, K_global = True, False, a.n_particles
+            n_streams = a.streams if a.streams > 0 else 3
+        failed, why = 0.0, None
+        try:
+            if form in forced_fail:
+                raise _ffi.PhyloError(-1, "forced failure of the '%s' form (PHYLO_BENCH_FAIL)" % form)
+            ctxs, single = make_contexts()
+            ctx = ctxs[0]
+            first_contact["exchange"] = ctx.comm_exchange_kind()
+            run(n_streams * batch, a.seed + 2000)
+            for c in ctxs:
+                c.sweep_fetch(arrays=False)
+        except (_ffi.PhyloError, TimeoutError, OSError) as e:
+            failed, why = 1.0, "%s: %s" % (type(e).__name__, e)
+        if (fs.max(failed) if fs else failed) == 0.0:
+            break
+        tried.append("%s form failed%s" % (form, (" here: " + why) if why else " on another rank"))
+        close_all()
+        ctxs, single, ctx = [], None, None
+        if world == 1:
+            raise SystemExit(why)
+    else:
+        raise SystemExit("rank %d: no form of the N = %d run worked: %s" % (rank, world, "; ".join(tried)))
+    if tried:
+        first_contact["fallback"] = "; ".join(tried)
     run(-(-max(a.warmup, 0) // batch) * batch, a.seed + 1000)   # W warm-up steps, rounded up to whole launch sets
     # the K steps, timed `repeats` times (each bracketed by the barrier; max over ranks), median reported: one repetition of
     # the default K lasts a few ms, too short to quote alone
     reps_dt = []
-    while True:
-        ctx.comm_barrier()
+    inner = 1
+    if independent:                                   # the ranks meet through files (~0.1 ms of skew): time >= 50 ms per bracket
         t0 = time.perf_counter()
         run(a.steps, a.seed)
-        ctx.comm_barrier()
-        reps_dt.append(ctx.comm_max(time.perf_counter() - t0))      # max over ranks (every rank takes the same decision below)
+        inner = max(1, int(gmax(0.05 / max(time.perf_counter() - t0, 1e-6)) + 0.5))
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(inner):
+            run(a.steps, a.seed)
+        barrier()
+        reps_dt.append(gmax(time.perf_counter() - t0) / inner)      # max over ranks (every rank takes the same decision below)
         if sum(reps_dt) * 1e3 >= a.min_timed_ms and len(reps_dt) >= 3:
             break
         if len(reps_dt) >= 400:
@@ -343,7 +388,7 @@ def main():
                 worst = max(worst, abs(out['logZ'] - ref['logZ']))
                 cols = slice(single.k0, single.k0 + single.K_local)
                 same = same and bool(np.array_equal(out['ancestors'], ref['ancestors'][:, cols]))
-            ctx.comm_barrier()                            # the other ranks wait for rank 0's oracle HERE, not inside a kernel's flag wait
+            barrier()                                     # the other ranks wait for rank 0's oracle HERE, not inside a kernel's flag wait
         parity = {"delta_logZ_max": worst, "ancestors_equal": same, "parity_seeds": n_seeds}
     prof_sweeps = 3
     merge_ms, merge_n = 0.0, 0
@@ -423,19 +468,45 @@ def main():
         if roof["hbm_frac"] is not None and roof["hbm_frac"] > 0.5:        # eager nodes on large rows: the store stream binds
             roof.update({"bound": "hbm", "achieved": roof["hbm_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": roof["hbm_frac"]})
 
+    # N > 1, sharded: the same steps once more as independent sweeps per rank (own contexts, no communicator): what N GPUs do
+    # without any exchange, next to which the sharded value shows the price of the global resampling
+    independent_rate = None
+    if world > 1 and not independent and not a.twisting and not os.environ.get('PHYLO_BENCH_NO_INDEPENDENT'):
+        Ks, sh, ns, cx, sg, c0, n_live = K_global, sharded, n_streams, ctxs, single, ctx, len(live)
+        try:
+            independent, sharded, K_global, n_streams = True, False, a.n_particles, (a.streams if a.streams > 0 else 3)
+            ctxs, single = make_contexts()
+            ctx = ctxs[0]
+            run(n_streams * batch, a.seed + 2000)
+            t0 = time.perf_counter()
+            run(a.steps, a.seed)
+            inner = max(1, int(gmax(0.05 / max(time.perf_counter() - t0, 1e-6)) + 0.5))
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(inner):
+                run(a.steps, a.seed)
+            barrier()
+            dti = gmax(time.perf_counter() - t0) / inner
+            independent_rate = float(a.n_particles) * S * (N - 1) * a.steps * world / dti
+        except (_ffi.PhyloError, TimeoutError, OSError):
+            independent_rate = None
+        while len(live) > n_live:
+            live.pop().close()
+        independent, sharded, K_global, n_streams, ctxs, single, ctx = False, sh, Ks, ns, cx, sg, c0
     if rank == 0:
         units_per_step = float(K_global) * S * (N - 1)
         if a.twisting:                             # + K M S C(N+1,3) look-ahead merges
             units_per_step += float(K_global) * a.M * S * ((N + 1) * N * (N - 1) / 6.0)
         line = {
-            "metric": "particle-site-likelihoods/sec", "value": units_per_step * a.steps / dt,
+            "metric": "particle-site-likelihoods/sec", "value": units_per_step * a.steps / dt * (world if independent else 1),
             "unit": "particle-site-likelihoods/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" if a.synthetic else "primate.p alignment (real sites), %s model parameters" % ("trained (%s)" % os.path.basename(a.params) if a.params else "untrained"),
             "config": {"workload": "%s N=%d S=%d, %s, K=%d per GPU (K_total=%d), lambda=10, full sweep of %d rank events"
                                    % (wname, N, S, ("JC69" if a.jcmodel else "GTR-init (jcmodel=false)") + (" + twisting M=%d" % a.M if a.twisting else ""),
                                       a.n_particles, K_global, N - 1),
-                       "parallelism": "particles sharded over %d GPU(s), global resampling" % world,
+                       "parallelism": ("independent sweeps of K=%d particles on each of %d GPUs, no exchange" % (a.n_particles, world)) if independent
+                                      else "particles sharded over %d GPU(s), global resampling" % world,
                        "sweeps_per_launch_set": batch, "contexts_in_flight": n_streams,
                        "sweeps_in_flight": n_streams * batch, "particles_in_flight": n_streams * batch * K_global},
             "timed_region": {"repeats": len(reps_dt), "ms_total": sum(reps_dt) * 1e3, "ms_per_step_min": min(reps_dt) / a.steps * 1e3,
@@ -453,6 +524,11 @@ def main():
         if parity is not None:
             line.update(parity)
         if world > 1 or sharded:
+            indep = None
+            if independent_rate is not None:
+                indep = {"value": independent_rate, "unit": "particle-site-likelihoods/s",
+                         "what": "the same %d steps as %d independent sweeps of K=%d per rank, no exchange: the N x one-GPU figure the sharded value is to "
+                                 "be read against" % (a.steps, world, a.n_particles)}
             # first contact with more than one device: what the run actually did, next to the one-GPU figures it should match
             n_coll = 0 if first_contact["exchange"] == 'p2p' else (N - 1) * (2 if not a.eager and not a.twisting else 1) - (1 if not a.eager and not a.twisting else 0)
             ref_us = None
@@ -465,7 +541,9 @@ def main():
                     pass
                 if ref_us:
                     break
-            line["multi_gpu"] = {"exchange": first_contact["exchange"], "fallback": first_contact["fallback"],
+            line["multi_gpu"] = {"form": "independent sweeps per rank" if independent else "one sweep's particles sharded over the ranks",
+                                 "independent_sweeps": indep,
+                                 "exchange": first_contact["exchange"], "fallback": first_contact["fallback"],
                                  "collective_calls_per_sweep_and_rank": n_coll,
                                  "merge_kernel": merge_kernel, "merge_avg_launch_us_rank0": avg_s * 1e6,
                                  "merge_avg_launch_us_one_gpu_profile": ref_us,
@@ -477,10 +555,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g, Q, pi, lam, a.jcmodel, a.n_particles, a.cpu_seconds, a.M if a.twisting else 0, lam_r)
         print(json.dumps(line), flush=True)
-    if single is not ctx:
-        single.close()
-    for c in reversed(ctxs):                          # sharers before the owner of the communicator
-        c.close()
+    close_all()                                       # (sharers before the owner of the communicator)
 
 
 if __name__ == '__main__':

@@ -46,3 +46,41 @@ def exchange_comm_id(rank, world, make_id, timeout=300.0):
         if time.time() - t0 > timeout:
             raise TimeoutError("rank %d: no RCCL id from rank 0 at %s after %.0f s" % (rank, path, timeout))
         time.sleep(0.01)
+
+
+class FileSync:
+    """Barrier and all-gather of one float between the ranks of ONE node through files in the rendezvous directory: what bench.py
+    falls back to when no communicator could be built (first contact with more than one GPU), so that the run still ends with a
+    measured line.  Polling files costs ~0.1 ms of skew: callers time regions much longer than that."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.n = rank, world, 0
+        self.dir = _dir()
+        os.makedirs(self.dir, exist_ok=True)
+
+    def allgather(self, value, timeout=300.0):
+        tag = "fsync_%d" % self.n
+        self.n += 1
+        path = os.path.join(self.dir, "%s_r%d" % (tag, self.rank))
+        with open(path + ".tmp", "w") as f:
+            f.write(repr(float(value)))
+        os.replace(path + ".tmp", path)
+        out, t0 = [], time.time()
+        for r in range(self.world):
+            p = os.path.join(self.dir, "%s_r%d" % (tag, r))
+            while True:
+                try:
+                    with open(p) as f:
+                        out.append(float(f.read()))
+                    break
+                except (OSError, ValueError):
+                    if time.time() - t0 > timeout:
+                        raise TimeoutError("rank %d: rank %d never reached %s" % (self.rank, r, tag))
+                    time.sleep(0.0002)
+        return out
+
+    def barrier(self):
+        self.allgather(0.0)
+
+    def max(self, value):
+        return max(self.allgather(value))

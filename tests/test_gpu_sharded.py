@@ -325,3 +325,49 @@ def test_runner_n_gpus_equals_single_process():
         assert str(r['newick']) == str(one['newick'])
         assert np.array_equal(r['log_weights'].view(np.uint64), one['log_weights'].view(np.uint64))
         np.testing.assert_array_equal(r['ancestors'], one['ancestors'])
+
+
+def _run_bench_ranks(world, extra_env, args):
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, PHYLO_RDZV_DIR=tmp, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29300 + os.getpid() % 600), PHYLO_COMM='hostshm',
+                       RANK=str(r), LOCAL_RANK='0', WORLD_SIZE=str(world))
+            env.update(extra_env)
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), '--gpus', str(world)] + args, env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+        outs = []
+        for p in procs:
+            out, err = p.communicate(timeout=300)
+            assert p.returncode == 0, err.decode()[-2000:]
+            outs.append(out.decode())
+        lines = [ln for ln in outs[0].splitlines() if ln.startswith('{')]
+        assert len(lines) == 1 and not any(ln.startswith('{') for o in outs[1:] for ln in o.splitlines())   # rank 0 prints the ONE line
+        import json
+        return json.loads(lines[0])
+
+
+def test_bench_py_at_two_ranks_reports_the_sharded_value_and_the_independent_figure():
+    """bench.py itself as the driver launches it at N = 2 (two processes on GPU 0, host-side collectives over hostshm): the
+    value is the sharded sweep's, 1 == N parity against the oracle holds, the independent-sweeps figure stands beside it."""
+    line = _run_bench_ranks(2, {}, ['--steps', '12', '--warmup', '2', '--n_particles', '64', '--min-timed-ms', '20'])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+    mg = line['multi_gpu']
+    assert mg['form'].startswith("one sweep's particles sharded") and mg['exchange'] == 'p2p' and mg['fallback'] is None
+    assert mg['independent_sweeps']['value'] > 0
+    assert line['delta_logZ_max'] == 0.0 and line['ancestors_equal'] is True
+    assert 'K_total=128' in line['config']['workload']
+
+
+@pytest.mark.parametrize("fail,form,exchange", [('default', "one sweep's particles sharded", 'hostshm'),
+                                                ('default,collective', 'independent sweeps per rank', 'none')])
+def test_bench_py_falls_back_form_by_form(fail, form, exchange):
+    """First contact gone wrong (forced): the device-side exchange fails -> every rank rebuilds on the collective path; that fails too
+    -> independent sweeps per rank, the ranks meeting through files; the line says what happened and still carries a value."""
+    line = _run_bench_ranks(2, {'PHYLO_BENCH_FAIL': fail}, ['--steps', '12', '--warmup', '2', '--n_particles', '64', '--min-timed-ms', '20'])
+    mg = line['multi_gpu']
+    assert mg['form'].startswith(form) and mg['exchange'] == exchange, mg
+    assert 'forced failure' in mg['fallback'] and line['value'] > 0
+    if form.startswith('independent'):
+        assert 'independent sweeps of K=64' in line['config']['parallelism'] and 'K_total=64' in line['config']['workload']
+        assert line['delta_logZ_max'] == 0.0
