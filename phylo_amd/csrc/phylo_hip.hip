@@ -55,6 +55,7 @@ struct env_switches {
     unsigned long long p2p_wait_ticks = PK_P2P_WAIT_TICKS;   // PHYLO_P2P_WAIT_S: bound of a flag wait of the device-side exchange
     size_t p2p_copy_words = 65536;       // PHYLO_P2P_COPY_WORDS: exchanges beyond this many doubles copy with many workgroups (tests lower it)
     int persist_nt = 256;                // PHYLO_PERSIST_NT: threads per workgroup of the one-launch sweep (256 or 512)
+    int scan_multi_min = 4096;           // PHYLO_SCAN_MULTI_MIN: groups of more weights than this are scanned by several workgroups
     void read() {
         eager_nodes = getenv("PHYLO_EAGER_NODES") != nullptr;
         rehearse_sharded = getenv("PHYLO_REHEARSE_SHARDED") != nullptr;
@@ -69,6 +70,7 @@ struct env_switches {
         grad_one_stream = getenv("PHYLO_GRAD_ONE_STREAM") != nullptr;
         grad_two_streams = getenv("PHYLO_GRAD_TWO_STREAMS") != nullptr;
         rev_host_lists = getenv("PHYLO_REV_HOST_LISTS") != nullptr;
+        { const char* e = getenv("PHYLO_SCAN_MULTI_MIN"); scan_multi_min = e ? atoi(e) : 4096; }
         no_spin_wait = getenv("PHYLO_NO_SPIN_WAIT") != nullptr;
         { const char* e = getenv("PHYLO_P2P"); no_p2p = e && atoi(e) == 0; }
         { const char* e = getenv("PHYLO_P2P_COPY_WORDS"); p2p_copy_words = e ? (size_t)atol(e) : 65536; }
@@ -510,6 +512,23 @@ int ensure_graph_state(phylo_ctx* c) {
 
 // resampling scan of G groups of Kg log-weights: the LDS form when a group fits (phylo_persist.h), else pk_resample_scan
 int launch_scan(phylo_ctx* c, const double* logw, int Kg, int G, uint64_t* cdf, double* lse, int lse_stride, int logz_R = 0) {
+    if (Kg > c->env.scan_multi_min && (cdf || lse)) {      // large groups: several workgroups per group, three small launches
+        pp_scan_multi_args a{};
+        a.logw = logw; a.Kg = Kg; a.B = (Kg + PP_SCAN_TILE - 1) / PP_SCAN_TILE;
+        void* ws = nullptr;
+        const size_t nb = (size_t)G * a.B;
+        CHK(scratch_get(c, 11, (nb * 2 + (size_t)G * Kg) * 8, &ws));
+        a.gmax = (double*)ws; a.bsum = (unsigned long long*)ws + nb; a.wbits = (unsigned long long*)ws + 2 * nb;
+        a.cdf = (unsigned long long*)cdf; a.lse_out = lse; a.lse_stride = lse_stride; a.logz_R = logz_R;
+        hipLaunchKernelGGL(pp_scan_multi_max, dim3(a.B, G), dim3(512), 0, c->stream, a);
+        CHK(launch_check(c, "pp_scan_multi_max"));
+        hipLaunchKernelGGL(pp_scan_multi_exp, dim3(a.B, G), dim3(512), 0, c->stream, a);
+        CHK(launch_check(c, "pp_scan_multi_exp"));
+        // (no cdf wanted: the log-normaliser's workgroup alone)
+        if (cdf) hipLaunchKernelGGL(pp_scan_multi_cdf, dim3(a.B + 1, G), dim3(512), 0, c->stream, a);
+        else { a.lse_only = 1; hipLaunchKernelGGL(pp_scan_multi_cdf, dim3(1, G), dim3(512), 0, c->stream, a); }
+        return launch_check(c, "pp_scan_multi_cdf");
+    }
     if (Kg <= 4096) {
         hipLaunchKernelGGL(pp_resample_scan<512>, dim3(G), dim3(512), pp_resample_scan_lds(Kg), c->stream, logw, Kg, cdf, lse, lse_stride, logz_R);
         return launch_check(c, "pp_resample_scan");

@@ -335,6 +335,155 @@ __global__ __launch_bounds__(NT) void pp_resample_scan(const double* logw, int K
     unsigned long long* out = reinterpret_cast<unsigned long long*>(cdf) + (size_t)g * Kg;
     for (int k = threadIdx.x; k < Kg; k += NT) out[k] = lcdf[k];
 }
+// ---- The same scan by SEVERAL workgroups per group (large groups: the replicated scan of a sharded sweep -- 8 GPUs x 2048 particles
+//      is one group of 16 384 weights, 27 us for the one workgroup above, as long as the merge beside it -- and any K beyond the
+//      LDS form).  Three small launches, a tile of 2048 weights per workgroup:
+//        pp_scan_multi_max   the tile's maximum (exact, any order);
+//        pp_scan_multi_exp   the group's maximum from the tiles', w = exp(logw - max) stored as bits, the tile's sum of the INTEGER
+//                            weights floor(w 2^44) (exact, any order);
+//        pp_scan_multi_cdf   tile b: the integer prefix sum behind the tiles before it; one more workgroup per group: the canonical
+//                            floating-point sum (column c = k mod 256, increasing k, then the tree -- the order of pp_scan, which
+//                            one workgroup has to walk) and the log-normaliser.
+//      Bit for bit pp_scan's results: only integer sums and maxima are re-associated.
+#define PP_SCAN_TILE 2048
+struct pp_scan_multi_args {
+    const double* logw;                // [G][Kg]
+    int Kg, B;                         // B = tiles per group
+    double* gmax;                      // [G][B]
+    unsigned long long* bsum;          // [G][B]
+    unsigned long long* wbits;         // [G][Kg]
+    unsigned long long* cdf;           // [G][Kg] or nullptr
+    double* lse_out;                   // or nullptr
+    int lse_stride, logz_R;
+    int lse_only;                      // pp_scan_multi_cdf: no cdf wanted, the launch is the log-normaliser's workgroup alone
+};
+__device__ __forceinline__ double pp_scan_multi_group_max(const pp_scan_multi_args& a, int g) {
+    double m = pp_gld(a.gmax + (size_t)g * a.B);
+    for (int b = 1; b < a.B; ++b) {
+        const double o = pp_gld(a.gmax + (size_t)g * a.B + b);
+        m = o > m ? o : m;
+    }
+    return m;
+}
+__global__ __launch_bounds__(512) void pp_scan_multi_max(const pp_scan_multi_args a) {
+    __shared__ double sh[8];
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* logw = a.logw + (size_t)g * a.Kg;
+    double m = -pm_inf();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = b * PP_SCAN_TILE + tid + 512 * j;
+        const double v = pp_gld(logw + (k < a.Kg ? k : a.Kg - 1));
+        if (k < a.Kg && !pm_isnan(v) && v > m) m = v;
+    }
+    m = pp_wave_max(m);
+    if (lane == 0) sh[wv] = m;
+    __syncthreads();
+    if (tid == 0) {
+        m = sh[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) m = sh[i] > m ? sh[i] : m;
+        a.gmax[(size_t)g * a.B + b] = m;
+    }
+}
+__global__ __launch_bounds__(512) void pp_scan_multi_exp(const pp_scan_multi_args a) {
+    __shared__ unsigned long long sh[8];
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double* logw = a.logw + (size_t)g * a.Kg;
+    const double m = pp_scan_multi_group_max(a, g);
+    const bool all_bad = !(m > -pm_inf()) || m == pm_inf();
+    double v[4], w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = b * PP_SCAN_TILE + tid + 512 * j;
+        v[j] = pp_gld(logw + (k < a.Kg ? k : a.Kg - 1));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                          // (straight-line, like pp_scan: the four evaluations overlap)
+        const bool nan = pm_isnan(v[j]);
+        const double e = pm_exp_nonpos(nan ? 0.0 : v[j] - m);
+        w[j] = all_bad ? 1.0 : (nan ? 0.0 : e);
+    }
+    unsigned long long local = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = b * PP_SCAN_TILE + tid + 512 * j;
+        if (k < a.Kg) {
+            a.wbits[(size_t)g * a.Kg + k] = pm_bits(w[j]);
+            local += all_bad ? 1ull : (unsigned long long)(w[j] * PM_CDF_SCALE);
+        }
+    }
+    const unsigned long long incl = pp_wave_incl_scan_u64(local, lane);
+    if (lane == 63) sh[wv] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += sh[i];
+        a.bsum[(size_t)g * a.B + b] = t;
+    }
+}
+__global__ __launch_bounds__(512) void pp_scan_multi_cdf(const pp_scan_multi_args a) {
+    __shared__ pp_scan_lds sh;
+    const int b = blockIdx.x, g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned long long* wb = a.wbits + (size_t)g * a.Kg;
+    const double m = pp_scan_multi_group_max(a, g);
+    const bool all_bad = !(m > -pm_inf()) || m == pm_inf();
+    if (b == a.B || a.lse_only) {                          // the canonical floating-point sum and the log-normaliser
+        if (!a.lse_out) return;
+        if (tid < 256) {                                   // (sixteen loads in flight, the additions in the order of pp_scan)
+            double col = 0.0;
+            for (int k0 = tid; k0 < a.Kg; k0 += 256 * 16) {
+                unsigned long long q[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = k0 + 256 * u;
+                    q[u] = pp_gld(wb + (k < a.Kg ? k : a.Kg - 1));
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (k0 + 256 * u < a.Kg) col = col + pm_from_bits(q[u]);
+            }
+            col = pp_wave_tree_sum(col);
+            if (lane == 0) sh.d[wv] = col;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const double sum = ((sh.d[0] + sh.d[1]) + sh.d[2]) + sh.d[3];
+            const double mm = all_bad ? 0.0 : m;
+            double* out = a.lse_out + (size_t)g * a.lse_stride;
+            *out = (mm + pp_log(sum)) - pp_log((double)a.Kg);
+            if (a.logz_R > 0) {                            // (the earlier elements of the row come from earlier launches)
+                double* row = out - (a.logz_R - 1);
+                double z = 0.0;
+                for (int r = 0; r < a.logz_R; ++r) z = z + row[r];
+                row[a.logz_R] = z;
+            }
+        }
+        return;
+    }
+    unsigned long long carry = 0;
+    for (int i = 0; i < b; ++i) carry += pp_gld(a.bsum + (size_t)g * a.B + i);
+    const int lo = b * PP_SCAN_TILE + 4 * tid;
+    unsigned long long e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        e[j] = (lo + j < a.Kg) ? (all_bad ? 1ull : (unsigned long long)(pm_from_bits(pp_gld(wb + lo + j)) * PM_CDF_SCALE)) : 0ull;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) e[j] += e[j - 1];
+    const unsigned long long local = e[3];
+    const unsigned long long incl = pp_wave_incl_scan_u64(local, lane);
+    if (lane == 63) sh.u[wv] = incl;
+    __syncthreads();
+    unsigned long long run = carry + incl - local;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < wv) run += sh.u[i];
+    unsigned long long* out = a.cdf + (size_t)g * a.Kg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (lo + j < a.Kg) out[lo + j] = run + e[j];
+}
 #define PP_SCAN_KERNEL_MAX_KG 16384    // 128 KiB of cdf in LDS, 1024 threads: the replicated scan of 8 GPUs x 2048 particles
 __host__ inline size_t pp_resample_scan_lds(int Kg) { return ((sizeof(pp_scan_lds) + 15) & ~(size_t)15) + (size_t)Kg * 8; }
 

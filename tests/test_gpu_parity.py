@@ -140,8 +140,8 @@ def test_tree_loglik_golden_from_reference(golden_dir):
 def test_resample_bit_exact_and_edge_cases(small):
     ctx = make_ctx(small[:3, :16], 2, O.jc_Q())
     rng = np.random.default_rng(4)
-    # 4097, 12000, 16384: the 1024-thread LDS scan (128 KiB of cdf); 20000: beyond LDS, the global-memory scan
-    for K in (1, 2, 255, 256, 1000, 2048, 4096, 4097, 5000, 12000, 16384, 20000):
+    # up to 4096: one workgroup, cdf in LDS; beyond: several workgroups per group (pp_scan_multi_*: tiles of 2048 weights)
+    for K in (1, 2, 255, 256, 1000, 2048, 4096, 4097, 5000, 6144, 12000, 16384, 20000, 100001):
         for scale in (0.5, 30.0, 400.0):
             lw = rng.normal(scale=scale, size=K) - 6000.0
             idx = ctx.resample(lw, seed=11, step=3)
@@ -156,6 +156,15 @@ def test_resample_bit_exact_and_edge_cases(small):
     assert not np.isin(idx, np.arange(0, 300, 7)).any()
     lw = np.full(50, -np.inf)                                      # degenerate: uniform
     np.testing.assert_array_equal(ctx.resample(lw, 5, 2), CO.resample(lw, 5, 2))
+    # the same edge cases across several workgroups: NaNs, one survivor in the last (ragged) tile, nothing finite
+    lw = rng.normal(scale=40.0, size=9000); lw[::11] = np.nan
+    np.testing.assert_array_equal(ctx.resample(lw, 5, 2), CO.resample(lw, 5, 2))
+    lw = np.full(9000, -np.inf); lw[8999] = 3.0
+    assert (ctx.resample(lw, 1, 1) == 8999).all()
+    lw = np.full(9000, -np.inf)
+    np.testing.assert_array_equal(ctx.resample(lw, 5, 2), CO.resample(lw, 5, 2))
+    lw = rng.normal(scale=20, size=(5, 10000)) - 500               # log Z of large rows (the log-normaliser's workgroup alone)
+    assert_bit_equal(ctx.log_zsmc(lw), CO.log_zsmc(lw), "log_zsmc, 10000 weights per row")
     # log Z
     lw = rng.normal(scale=20, size=(11, 777)) - 500
     z = ctx.log_zsmc(lw)
