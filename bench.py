@@ -324,6 +324,35 @@ def main():
         raise SystemExit("rank %d: no form of the N = %d run worked: %s" % (rank, world, "; ".join(tried)))
     if tried:
         first_contact["fallback"] = "; ".join(tried)
+    # Sharded on more than one rank: remote children of a merge are read from a local cache filled once per sweep, or in place over
+    # the peer mapping (PHYLO_NO_REMOTE_CACHE=1).  Which is faster depends on the links (on ONE GPU the copy is pure overhead, over
+    # xGMI a remote row is otherwise fetched by every launch and XCD): both forms run a few launch sets here, the faster one is kept.
+    first_contact["remote_cache"] = None
+    if world > 1 and not independent and not a.twisting and 'PHYLO_NO_REMOTE_CACHE' not in os.environ and not os.environ.get('PHYLO_BENCH_NO_CACHE_PROBE'):
+        def probe():
+            run(n_streams * batch, a.seed + 2100)
+            barrier()
+            t0 = time.perf_counter()
+            for rep in range(3):
+                run(n_streams * batch, a.seed + 2200 + rep)
+            barrier()
+            return gmax(time.perf_counter() - t0) / 3
+        t_on = probe()
+        used, cap = ctx.debug_remote_cache()
+        close_all()
+        os.environ['PHYLO_NO_REMOTE_CACHE'] = '1'
+        ctxs, single = make_contexts()
+        ctx = ctxs[0]
+        t_off = probe()
+        keep_cache = t_on <= t_off
+        if keep_cache:
+            close_all()
+            del os.environ['PHYLO_NO_REMOTE_CACHE']
+            ctxs, single = make_contexts()
+            ctx = ctxs[0]
+            run(n_streams * batch, a.seed + 2000)
+        first_contact["remote_cache"] = {"kept": "cache" if keep_cache else "in place", "ms_per_launch_set_with_cache": t_on * 1e3,
+                                         "ms_per_launch_set_in_place": t_off * 1e3, "slots_used_rank0": used, "slots": cap}
     run(-(-max(a.warmup, 0) // batch) * batch, a.seed + 1000)   # W warm-up steps, rounded up to whole launch sets
     # the K steps, timed `repeats` times (each bracketed by the barrier; max over ranks), median reported: one repetition of
     # the default K lasts a few ms, too short to quote alone
@@ -544,6 +573,7 @@ def main():
             line["multi_gpu"] = {"form": "independent sweeps per rank" if independent else "one sweep's particles sharded over the ranks",
                                  "independent_sweeps": indep,
                                  "exchange": first_contact["exchange"], "fallback": first_contact["fallback"],
+                                 "remote_children": first_contact.get("remote_cache"),
                                  "collective_calls_per_sweep_and_rank": n_coll,
                                  "merge_kernel": merge_kernel, "merge_avg_launch_us_rank0": avg_s * 1e6,
                                  "merge_avg_launch_us_one_gpu_profile": ref_us,

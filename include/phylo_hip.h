@@ -262,6 +262,10 @@ int phylo_comm_barrier(phylo_ctx* ctx);
  * host-mediated test transport (PHYLO_COMM=hostshm); 3 the device-side exchange (every rank writes into the peers' hipIpc-mapped
  * slabs and raises a flag: no collective call per rank event; the default when sharded, PHYLO_P2P=0 turns it off). */
 int phylo_comm_exchange_kind(const phylo_ctx* ctx);
+/* Sharded contexts keep the remote nodes their particles merge in a local cache, fetched once per sweep over the peer mapping
+ * (pk_pull_remote_children; PHYLO_NO_REMOTE_CACHE=1: every remote child is read in place, PHYLO_REMOTE_CACHE_CAP: slots).
+ * used: slots claimed by the last sweep (more than cap: the rest was read in place); cap: slots (0: no cache). */
+int phylo_debug_remote_cache(phylo_ctx* ctx, int* used, int* cap);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ EXPORTS = [
     "phylo_forest_loglik", "phylo_tree_loglik", "phylo_resample", "phylo_log_zsmc", "phylo_sweep",
     "phylo_sweep_async", "phylo_sweep_batch_async", "phylo_sweep_batch_begin", "phylo_sweep_fetch_logz", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_step_a", "phylo_sweep_step_group", "phylo_sweep_finish", "phylo_sweep_fetch",
     "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
-    "phylo_math_probe", "phylo_debug_stamps", "phylo_debug_reverse_lists", "phylo_debug_device_lists", "phylo_debug_device_lists_of",
+    "phylo_math_probe", "phylo_debug_stamps", "phylo_debug_reverse_lists", "phylo_debug_device_lists", "phylo_debug_device_lists_of", "phylo_debug_remote_cache",
     "phylo_site_tile", "phylo_set_site_tile", "phylo_get_site_tile",
     "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_allgather", "phylo_comm_max", "phylo_comm_barrier",
     "phylo_comm_exchange_kind",
@@ -368,6 +368,12 @@ class Context:
         out = np.empty((world,) + a.shape, dtype=a.dtype)
         self._check(self._lib.phylo_comm_allgather(self._h, _ptr(a), C.c_size_t(a.nbytes), _ptr(out)))
         return out
+
+    def debug_remote_cache(self):
+        """(slots claimed by the last sweep, slots) of the local cache of remote nodes of a sharded context ((0, 0): no cache)"""
+        used, cap = C.c_int(0), C.c_int(0)
+        self._check(self._lib.phylo_debug_remote_cache(self._h, C.byref(used), C.byref(cap)))
+        return used.value, cap.value
 
     def comm_exchange_kind(self):
         """'none' | 'rccl' | 'hostshm' | 'p2p': how the K-vectors of a rank event reach the other ranks"""

@@ -49,12 +49,13 @@ struct sweep_run {                       // a sweep being issued rank event by r
 struct env_switches {
     bool eager_nodes = false, rehearse_sharded = false, replicated_book = false, fuse_scan = false,
          book_one_per_wave = false, merge_pair_form = false, no_leaf_codes = false, one_launch = false,
-         persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, rev_host_lists = false, no_spin_wait = false,
+         persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, rev_host_lists = false, no_remote_cache = false, no_spin_wait = false,
          no_p2p = false;
     int persist_wgs = 0;                 // PHYLO_PERSIST_WGS: resident workgroups of the one-launch sweep (0 = default)
     unsigned long long p2p_wait_ticks = PK_P2P_WAIT_TICKS;   // PHYLO_P2P_WAIT_S: bound of a flag wait of the device-side exchange
     size_t p2p_copy_words = 65536;       // PHYLO_P2P_COPY_WORDS: exchanges beyond this many doubles copy with many workgroups (tests lower it)
     int persist_nt = 256;                // PHYLO_PERSIST_NT: threads per workgroup of the one-launch sweep (256 or 512)
+    int remote_cache_cap = 0;            // PHYLO_REMOTE_CACHE_CAP: slots of the local cache of remote nodes (0 = 512 MB worth; tests lower it)
     int scan_multi_min = 4096;           // PHYLO_SCAN_MULTI_MIN: groups of more weights than this are scanned by several workgroups
     void read() {
         eager_nodes = getenv("PHYLO_EAGER_NODES") != nullptr;
@@ -70,6 +71,8 @@ struct env_switches {
         grad_one_stream = getenv("PHYLO_GRAD_ONE_STREAM") != nullptr;
         grad_two_streams = getenv("PHYLO_GRAD_TWO_STREAMS") != nullptr;
         rev_host_lists = getenv("PHYLO_REV_HOST_LISTS") != nullptr;
+        no_remote_cache = getenv("PHYLO_NO_REMOTE_CACHE") != nullptr;
+        { const char* e = getenv("PHYLO_REMOTE_CACHE_CAP"); remote_cache_cap = e ? atoi(e) : 0; }
         { const char* e = getenv("PHYLO_SCAN_MULTI_MIN"); scan_multi_min = e ? atoi(e) : 4096; }
         no_spin_wait = getenv("PHYLO_NO_SPIN_WAIT") != nullptr;
         { const char* e = getenv("PHYLO_P2P"); no_p2p = e && atoi(e) == 0; }
@@ -146,6 +149,10 @@ struct phylo_ctx {
     unsigned int* d_counter = nullptr;   // [0] scan->bookkeeping flag, [1] hand-off timeout word
     unsigned int epoch = 0;              // monotone hand-off epoch (never reset, never 0)
     const double** d_pool_ptrs = nullptr; // [world] pool base of every rank (peer mappings)
+    // sharded: remote nodes merged by this rank, fetched once per sweep (pk_pull_remote_children)
+    int32_t* d_mirror = nullptr;         // [(N-1) K + 4]: node -> slot + 1 | 0 | -2; the last four words: [0] slots taken
+    double* d_cache = nullptr;           // [cache_cap][S][4]
+    int cache_cap = 0;
     // twisted proposal (allocated on first use)
     int32_t *d_roots_ad = nullptr, *d_cnt_ad = nullptr;
     double *d_rootll_ad = nullptr, *d_chosen = nullptr, *d_tw_b = nullptr, *d_tw_P = nullptr, *d_pot = nullptr;
@@ -348,7 +355,7 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_tilev = nullptr;
     void* ptrs[] = {c->d_pool, c->d_nodell, c->d_bl, c->d_br, c->d_Pmat, c->d_logw, c->d_ll, c->d_aux, c->d_lse, c->d_group_seeds,
                     c->d_tables, (void*)c->d_tab_ptrs, c->d_child, c->d_merges, c->d_anc,
-                    c->d_cdf[0], c->d_cdf[1], c->d_counter, (void*)c->d_pool_ptrs, c->d_mark, c->d_sync};
+                    c->d_cdf[0], c->d_cdf[1], c->d_counter, (void*)c->d_pool_ptrs, c->d_mark, c->d_sync, c->d_mirror, c->d_cache};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->d_pool = c->d_nodell = c->d_bl = c->d_br = c->d_Pmat = c->d_logw = c->d_ll = c->d_aux = c->d_lse = nullptr;
@@ -363,6 +370,9 @@ void free_sweep_state(phylo_ctx* c) {
     c->d_pool_ptrs = nullptr;
     c->d_mark = nullptr;
     c->d_sync = nullptr;
+    c->d_mirror = nullptr;
+    c->d_cache = nullptr;
+    c->cache_cap = 0;
 }
 
 int alloc_sweep_state(phylo_ctx* c) {
@@ -427,6 +437,17 @@ int alloc_sweep_state(phylo_ctx* c) {
     int rc = phylo_comm_map_pools(c->comm, c->d_pool, &ptrs, c->stream, &c->err);
     if (rc != PHYLO_OK) return rc;
     HIPCHK(c, hipMemcpy((void*)c->d_pool_ptrs, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice));
+    if ((c->world > 1 || c->env.rehearse_sharded) && !c->env.no_remote_cache) {
+        // the local cache of remote nodes: up to 512 MB of rows (primate.p: 17 000 nodes; 128 x 50 000: 320), the rest in place
+        const size_t node_bytes = (size_t)S * 32;
+        size_t cap = ((size_t)512 << 20) / node_bytes;
+        if (c->env.remote_cache_cap > 0) cap = (size_t)c->env.remote_cache_cap;
+        if (cap > R * K) cap = R * K;
+        if (cap < 1) cap = 1;
+        c->cache_cap = (int)cap;
+        CHK(dalloc(c, &c->d_mirror, R * K + 4));
+        CHK(dalloc(c, &c->d_cache, cap * (size_t)S * 4));
+    }
     CHK(dalloc(c, &c->d_tab_ptrs, (size_t)c->world));
     rc = phylo_comm_map_extra(c->comm, c->d_tables, &ptrs, c->stream, &c->err);
     if (rc != PHYLO_OK) return rc;
@@ -1101,6 +1122,7 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
         launches += 1;
     }
     CHK(launch_check(c, "pk_init_tables"));
+    if (c->d_mirror) HIPCHK(c, hipMemsetAsync(c->d_mirror, 0, ((size_t)R * K + 4) * 4, c->stream));   // the cache of remote nodes is per sweep
     c->run = sweep_run{};
     c->run.seed = seed; c->run.flags = flags; c->run.M = M;
     c->run.twist = twist; c->run.graph = graph; c->run.lazy = lazy; c->run.timek = timek; c->run.fuse_scan = fuse_scan;
@@ -1292,6 +1314,7 @@ static int sweep_step_a(phylo_ctx* c) {
     b.cdf = c->d_cdf[r & 1];
     b.Kg = K / G; b.group_seeds = G > 1 ? c->d_group_seeds : nullptr;
     b.leaves = c->d_leaves; b.pool = c->d_pool; b.pool_ptrs = c->d_pool_ptrs;
+    b.mirror = (c->run.twist || c->env.replicated_book) ? nullptr : c->d_mirror; b.cache = c->d_cache; b.cache_cap = c->cache_cap;
     b.leaf_codes = c->leaves_coded ? c->d_leaf_codes : nullptr;
     b.lazy = 1; b.mark = c->d_mark; b.child_all = c->d_child; b.Pmat_all = c->d_Pmat;
     if (c->run.mat_by_draws) {
@@ -1359,6 +1382,9 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
         b.loglam_l = pm_log(b.lam_l); b.loglam_r = pm_log(b.lam_r);
         b.ll_tilde0 = ll_tilde0;
         b.leaves = c->d_leaves; b.pool = c->d_pool; b.pool_ptrs = c->d_pool_ptrs;
+        // the cache of remote nodes is filled by the bookkeeping launch, which must come behind the owners' writes of this rank
+        // event's adopted nodes: not so with replicated bookkeeping (and the twisted proposal reads its roots elsewhere)
+        b.mirror = (twist || c->env.replicated_book) ? nullptr : c->d_mirror; b.cache = c->d_cache; b.cache_cap = c->cache_cap;
         b.leaf_codes = c->leaves_coded ? c->d_leaf_codes : nullptr;
         b.Pmat = c->d_Pmat + (size_t)r * Kl * 32;
         b.pi = c->d_pi;
@@ -2474,6 +2500,20 @@ int phylo_comm_share(phylo_ctx* c, phylo_ctx* owner) {
     CHK(alloc_sweep_state(c));                             // collective: every rank maps every peer's pool here
     CHK(refresh_leaf_ll(c));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PHYLO_OK;
+}
+
+int phylo_debug_remote_cache(phylo_ctx* c, int* used, int* cap) {
+    CHK(bind(c));
+    if (!used || !cap) return fail(c, PHYLO_EINVAL, "phylo_debug_remote_cache: NULL argument");
+    *used = 0;
+    *cap = c->cache_cap;
+    if (c->d_mirror) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        int32_t n = 0;
+        HIPCHK(c, hipMemcpy(&n, c->d_mirror + (size_t)(c->N - 1) * c->K, 4, hipMemcpyDeviceToHost));
+        *used = n;
+    }
     return PHYLO_OK;
 }
 

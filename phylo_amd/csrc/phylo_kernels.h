@@ -583,6 +583,11 @@ struct pk_rank_args {
     const uint8_t* leaf_codes;                            // [N][S] 0..3 one-hot state, 4 all-ones; NULL if some row is neither
     double* pool;                                         // [(N-1)][Kloc][S][4]: this rank's nodes
     const double* const* pool_ptrs;                       // [world]: every rank's pool as mapped in this process
+    // sharded: remote nodes this rank has merged once are kept in a local cache (pk_pull_remote_children); mirror[node - N] is
+    // 0 = not here, slot + 1, or -2 = the cache was full (read in place).  NULL: every remote child is read in place.
+    int32_t* mirror;                                      // [(N-1) K], then [0] = slots taken
+    double* cache;                                        // [cache_cap][S][4]
+    int cache_cap;
     const double* Pmat;                                   // [Kloc][32] of this rank
     const double* pi;
     double* logw_r; double* ll_r;                         // [K] rows (global columns)
@@ -1000,6 +1005,55 @@ __device__ __forceinline__ void pk_book_packed(const pk_rank_args& a, int kg, bo
     __syncthreads();
 }
 
+// ---- Sharded sweep: the local cache of remote nodes.  Over xGMI a remote row is fetched again by every launch that touches it (the
+//      mapping of a peer's memory is cached in L2 for the length of a kernel at best) and by every XCD, while the genealogy makes
+//      thousands of particles merge the same few nodes: the FIRST particle of this rank whose bookkeeping picks a remote node as a
+//      child claims its mirror entry (compare-and-swap), takes a slot and its wave copies the row, once per sweep; every later merge
+//      (this rank event's included: the copy is complete when the bookkeeping launch ends) reads the local copy (pk_node_ptr).
+//      The cache is bounded: when it is full the entry says so (-2) and the node is read in place as before.  Same bits either way.
+__device__ __forceinline__ bool pk_remote_node(const pk_rank_args& a, int id, int& x, const double*& src) {
+    if (id < a.N) return false;
+    x = id - a.N;
+    const int rho = x / a.K, kap = x - rho * a.K, owner = kap / a.Kloc;
+    if (owner * a.Kloc == a.k0) return false;
+    src = a.pool_ptrs[owner] + ((size_t)rho * a.Kloc + (kap - owner * a.Kloc)) * (size_t)a.S * 4;
+    return true;
+}
+// one lane: claim node `id` for this rank's cache; the slot to fill, or -1 (local, a leaf, somebody else's, or no room)
+__device__ __forceinline__ int pk_cache_claim(const pk_rank_args& a, int id) {
+    int x;
+    const double* src;
+    if (!pk_remote_node(a, id, x, src)) return -1;
+    if (__hip_atomic_load(a.mirror + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
+    int expected = 0;
+    if (!__hip_atomic_compare_exchange_strong(a.mirror + x, &expected, -1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return -1;
+    const int slot = __hip_atomic_fetch_add(a.mirror + (size_t)(a.N - 1) * a.K, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (slot >= a.cache_cap) {
+        __hip_atomic_store(a.mirror + x, -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return -1;
+    }
+    return slot;
+}
+// the whole wave: copy node `id` (wave-uniform, claimed with slot `slot`) into the cache, then publish the slot
+__device__ __forceinline__ void pk_cache_fill(const pk_rank_args& a, int id, int slot, int lane) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int cu4;
+    typedef __attribute__((address_space(1))) const cu4 gsrc_t;
+    typedef __attribute__((address_space(1))) cu4 gdst_t;
+    int x;
+    const double* srcd;
+    pk_remote_node(a, id, x, srcd);
+    const char* src = (const char*)srcd;
+    char* dst = (char*)(a.cache + (size_t)slot * (size_t)a.S * 4);
+    const size_t bytes = (size_t)a.S * 32;
+    size_t o = (size_t)lane * 16;
+    for (; o + 3 * 1024 < bytes; o += 4 * 1024) {          // four 16-byte loads per lane in flight (a remote round trip each)
+        const cu4 v0 = *(gsrc_t*)(src + o), v1 = *(gsrc_t*)(src + o + 1024), v2 = *(gsrc_t*)(src + o + 2048), v3 = *(gsrc_t*)(src + o + 3072);
+        *(gdst_t*)(dst + o) = v0; *(gdst_t*)(dst + o + 1024) = v1; *(gdst_t*)(dst + o + 2048) = v2; *(gdst_t*)(dst + o + 3072) = v3;
+    }
+    for (; o < bytes; o += 1024) *(gdst_t*)(dst + o) = *(gsrc_t*)(src + o);
+    if (lane == 0) __hip_atomic_store(a.mirror + x, slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int LP>
 __global__ __launch_bounds__(64) void pk_rank_book_packed(const pk_rank_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1019,6 +1073,17 @@ __global__ __launch_bounds__(64) void pk_rank_book_packed(const pk_rank_args a) 
     if (a.lazy && a.r > 0 && sl == 0) {
         const int anc = L.misc[3];
         a.mark[(size_t)(a.r - 1) * a.K + anc] = 1u;   // plain store: every adopter writes the same value
+    }
+    if (a.mirror && a.r > 0) {                        // (uniform) sharded: new remote children into the local cache, by the whole wave
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int id = L.misc[c];
+            const int slot = (local && sl == 0) ? pk_cache_claim(a, id) : -1;
+            for (int g2 = 0; g2 < 64 / LP; ++g2) {
+                const int s2 = __shfl(slot, g2 * LP, 64), id2 = __shfl(id, g2 * LP, 64);
+                if (s2 >= 0) pk_cache_fill(a, id2, s2, lane);
+            }
+        }
     }
 }
 
@@ -1222,6 +1287,14 @@ __global__ __launch_bounds__(64) void pk_rank_book(const pk_rank_args a) {
         const int anc = L.misc[3];                    // every rank sees every adoption; the OWNER of the node writes it
         a.mark[(size_t)(a.r - 1) * a.K + anc] = 1u;  // plain store: every adopter writes the same value (no contended atomics)
     }
+    if (a.mirror && a.r > 0 && local) {               // (uniform) sharded: new remote children into the local cache
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int id = L.misc[c];
+            const int slot = __shfl(threadIdx.x == 0 ? pk_cache_claim(a, id) : -1, 0, 64);
+            if (slot >= 0) pk_cache_fill(a, id, slot, threadIdx.x);
+        }
+    }
 }
 
 // Scan + bookkeeping in ONE launch: workgroup 0 (256 threads) runs the resampling scan of log w_{r-1} and
@@ -1269,6 +1342,10 @@ __device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int 
     if (id < a.N) return a.leaves + (size_t)id * node_sz;
     if (a.Kloc == a.K) return a.pool + (size_t)(id - a.N) * node_sz;      // one rank: no dependent load of the owner's base
     const int x = id - a.N, rho = x / a.K, kap = x - rho * a.K, owner = kap / a.Kloc;
+    if (a.mirror && owner * a.Kloc != a.k0) {              // a remote node this rank has fetched already: its local copy
+        const int slot = a.mirror[x];
+        if (slot > 0) return a.cache + (size_t)(slot - 1) * node_sz;
+    }
     return a.pool_ptrs[owner] + ((size_t)rho * a.Kloc + (kap - owner * a.Kloc)) * node_sz;
 }
 

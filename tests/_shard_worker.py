@@ -110,8 +110,9 @@ def main():
     t = ctx.comm_max(float(rank))
     assert t == world - 1, t
     ctx.comm_barrier()
+    cache_used, cache_cap = ctx_report.debug_remote_cache()    # (before sweep_node: it may run further kernels)
     node = ctx_report.sweep_node(N - 2, ctx.K_local - 1)
-    np.savez(out, log_weights=res['log_weights'], log_likelihood=res['log_likelihood'], ancestors=res['ancestors'],
+    np.savez(out, cache_used=cache_used, cache_cap=cache_cap, log_weights=res['log_weights'], log_likelihood=res['log_likelihood'], ancestors=res['ancestors'],
              merges=res['merges'], left_branches=res['left_branches'], logZ=res['logZ'], node=node, k0=ctx_report.k0,
              first_logZ=res.get('first_logZ', res['logZ']))
     for c in reversed(others):

@@ -47,7 +47,8 @@ def run_world(world, K, dataset, seed, jc, n_sweeps=1, transport='hostshm', extr
 
 @pytest.mark.parametrize("world,K,jc,form", [(2, 64, True, 'default'), (3, 96, False, 'default'), (2, 64, False, 'replicated'),
                                              (2, 64, False, 'eager'), (3, 96, True, 'eager'),
-                                             (2, 64, True, 'collective'), (3, 96, False, 'collective'), (2, 64, False, 'eager-collective')])
+                                             (2, 64, True, 'collective'), (3, 96, False, 'collective'), (2, 64, False, 'eager-collective'),
+                                             (2, 64, False, 'no-cache'), (3, 96, False, 'tiny-cache'), (2, 64, False, 'eager-tiny-cache')])
 def test_sharded_sweep_bit_identical(world, K, jc, form):
     """default: lazy nodes, every rank advances only its own particles' root tables and reads an adopted ancestor's rows
     from the owner's slab (peer mapping), adopted nodes are marked from the replicated index search and written by their
@@ -56,7 +57,10 @@ def test_sharded_sweep_bit_identical(world, K, jc, form):
     dataset, seed, n_sweeps = 'primate_data', 4, 2
     env = {'replicated': {'PHYLO_REPLICATED_BOOK': '1'}, 'eager': {'PHYLO_EAGER_NODES': '1'},
            'collective': {'PHYLO_P2P': '0'},                # the all-gather per rank event instead of the device-side exchange
-           'eager-collective': {'PHYLO_EAGER_NODES': '1', 'PHYLO_P2P': '0'}}.get(form)
+           'eager-collective': {'PHYLO_EAGER_NODES': '1', 'PHYLO_P2P': '0'},
+           'no-cache': {'PHYLO_NO_REMOTE_CACHE': '1'},      # every remote child read in place (the form before the cache)
+           'tiny-cache': {'PHYLO_REMOTE_CACHE_CAP': '3'},   # the cache fills up: the rest is read in place
+           'eager-tiny-cache': {'PHYLO_EAGER_NODES': '1', 'PHYLO_REMOTE_CACHE_CAP': '2'}}.get(form)
     parts = run_world(world, K, dataset, seed, jc, n_sweeps=n_sweeps, extra_env=env)
     g = load_dataset(dataset)['genome']
     N = g.shape[0]
@@ -75,6 +79,16 @@ def test_sharded_sweep_bit_identical(world, K, jc, form):
         assert np.array_equal(p['node'].view(np.uint64), ref['nodes'][N - 2, (r + 1) * Kl - 1].view(np.uint64))
     # remote children were really exercised: some ancestor of a rank-0 particle lives on another rank
     assert (parts[0]['ancestors'] >= Kl).any()
+    # ... and went through the local cache of remote nodes (fetched once per sweep), unless it is switched off / too small
+    used, cap = [int(p['cache_used']) for p in parts], [int(p['cache_cap']) for p in parts]
+    if form == 'no-cache':
+        assert cap == [0] * world and used == [0] * world
+    elif form == 'replicated':                               # (bookkeeping ahead of the owners' writes: remote nodes in place)
+        assert used == [0] * world
+    elif 'tiny' in form:
+        assert max(used) > cap[0] > 0, (used, cap)           # more nodes wanted than slots: the overflow path ran
+    else:
+        assert min(cap) > 0 and max(used) > 0, (used, cap)
 
 
 def test_sharded_lazy_nodes_bit_identical():
