@@ -570,7 +570,15 @@ def main():
                     pass
                 if ref_us:
                     break
+            # where the particles of a sweep live: a context's K = batch x K_total particle indices are sharded by contiguous ranges, so with
+            # batch >= N a sweep's K_total particles lie on one rank or straddle a boundary; only straddling sweeps merge remote children
+            kl_ctx = K_global * batch // max(world, 1)
+            straddling = sum(1 for gi in range(batch) if (gi * K_global) // kl_ctx != ((gi + 1) * K_global - 1) // kl_ctx)
             line["multi_gpu"] = {"form": "independent sweeps per rank" if independent else "one sweep's particles sharded over the ranks",
+                                 "sweeps_per_launch_set": batch, "sweeps_whose_particles_straddle_ranks": None if independent else straddling,
+                                 "layout_note": None if independent else
+                                 "every rank scans and exchanges the weights of all %d sweeps of a launch set; a sweep whose K_total particles lie on one "
+                                 "rank reads no remote child (with --batch 1 every sweep is spread over all ranks)" % batch,
                                  "independent_sweeps": indep,
                                  "exchange": first_contact["exchange"], "fallback": first_contact["fallback"],
                                  "remote_children": first_contact.get("remote_cache"),
