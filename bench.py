@@ -249,7 +249,10 @@ def main():
         nb = n // batch
         if independent:
             seed0 += rank * 1000003                       # every rank its own sweeps
-        if sharded:
+        # device-side exchange: every context has its own slab, flags and stream and no communicator call per rank event, so whole
+        # sweeps are issued like on one GPU (PHYLO_BENCH_STEPWISE=1: the rank-event-by-rank-event loop below anyway)
+        stepwise = sharded and (first_contact["exchange"] != 'p2p' or bool(os.environ.get('PHYLO_BENCH_STEPWISE')))
+        if stepwise:
             # the contexts in flight advance rank event by rank event, so every rank issues the collectives of the shared
             # communicator in the same order; each context carries `batch` independent sweeps (its K = batch * K_global
             # particle indices sharded by contiguous ranges).  One collective per context and rank event lets the
