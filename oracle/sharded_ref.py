@@ -12,7 +12,9 @@ resampling.  Every rank derives all K resampling indices (the weights are replic
 nodes of the previous rank event were adopted; it writes them, a barrier orders the writes, then everybody merges.  A
 read of a node that was never written is an error in this model.  Per rank event the ranks all-gather three K-vectors
 (log-weights, log-likelihoods, node log-likelihoods); a child node owned by another rank is fetched from its
-owner when (and only when) it is merged.  `comm` needs all_gather(np.ndarray) -> list of arrays and
+owner when (and only when) it is merged -- once per sweep and rank: the row is kept in a local cache (the GPU path's
+pk_cache_claim / pk_cache_fill; cache_slots bounds it, a node that finds it full is fetched again at every merge, i.e. read in
+place).  `comm` needs all_gather(np.ndarray) -> list of arrays and
 fetch_node(owner, key) (tests wire these to torch.distributed gloo).  The result must equal cpu_ref.sweep.
 """
 from __future__ import annotations
@@ -23,7 +25,7 @@ from . import cpu_ref as O
 
 
 def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, flags=O.QUIRK_Q1_RAW_Q, local_tables=False,
-                  lazy=False):
+                  lazy=False, cache_slots=None):
     """lazy='draws': like lazy=True, but every owner finds ITS adopted nodes from the K draw thresholds (the GPU's
     pk_materialize_by_draws: k is adopted iff some mulhi64(draw, total) lies in [cdf[k-1], cdf[k])) instead of from the K indices."""
     N, S, A = genome.shape
@@ -37,6 +39,7 @@ def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, f
     pool = {}                                                # (r, k) -> [S,4] for LOCAL k only (written nodes)
     unwritten = {}                                           # lazy: nodes computed for their likelihood but not written
     fetched = 0
+    cache, cache_full = {}, set()                            # remote nodes kept locally (None: unbounded; 0: none, always in place)
     log_weights, log_lik = np.zeros((N - 1, K)), np.zeros((N - 1, K))
     bls, brs = np.zeros((N - 1, Kl)), np.zeros((N - 1, Kl))
     ancestors = np.zeros((max(N - 2, 0), K), dtype=np.int64)
@@ -50,8 +53,16 @@ def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, f
         owner = k_ // Kl
         if owner == rank:
             return pool[(r_, k_)]
+        if (r_, k_) in cache:
+            return cache[(r_, k_)]
         fetched += 1
-        return comm.fetch_node(owner, (r_, k_))              # read in place over xGMI on the GPU path
+        row = comm.fetch_node(owner, (r_, k_))               # over xGMI on the GPU path
+        if (r_, k_) not in cache_full:
+            if cache_slots is None or len(cache) < cache_slots:
+                cache[(r_, k_)] = row                        # first merge of this node on this rank: its local copy from now on
+            else:
+                cache_full.add((r_, k_))                     # no room: this node stays remote for the rest of the sweep
+        return row
 
     for r in range(N - 1):
         n = N - r
@@ -118,4 +129,4 @@ def sweep_sharded(comm, rank, world, genome, Q, pi_1xA, lam_l, lam_r, K, seed, f
             roots[other], cnt[other], rootll[other] = -1, -1, np.nan
     logZ = O.compute_log_ZSMC(np.concatenate([np.zeros((1, K)), log_weights]))
     return {'log_weights': log_weights, 'log_likelihood': log_lik, 'ancestors': ancestors, 'logZ': logZ,
-            'remote_fetches': fetched}
+            'remote_fetches': fetched, 'cached_nodes': len(cache), 'cache_overflow': len(cache_full)}

@@ -120,6 +120,17 @@ def _worker(rank, world, port, K, seed, tmp, local_tables, lazy, flags=False):
     np.testing.assert_array_equal(out['ancestors'], ref['ancestors'])
     np.testing.assert_allclose(out['log_weights'], ref['log_weights'], rtol=1e-12)
     assert abs(out['logZ'] - ref['logZ']) < 1e-9 * abs(ref['logZ'])
+    # the local cache of remote nodes: unbounded, every remote node crosses once; two slots: same results, the overflow is read
+    # in place at every merge; none (the form before the cache): more fetches than nodes as soon as a node is merged twice
+    assert out['remote_fetches'] == out['cached_nodes'] and out['cache_overflow'] == 0
+    if not flags:
+        tiny = sweep_sharded(comm, rank, world, g, Q, pi, lam, lam, K, seed, local_tables=local_tables, lazy=lazy, cache_slots=2)
+        none = sweep_sharded(comm, rank, world, g, Q, pi, lam, lam, K, seed, local_tables=local_tables, lazy=lazy, cache_slots=0)
+        for o in (tiny, none):
+            np.testing.assert_array_equal(o['ancestors'], ref['ancestors'])
+            assert np.array_equal(o['log_weights'], out['log_weights']) and o['logZ'] == out['logZ']
+        assert tiny['cached_nodes'] <= 2 and none['cached_nodes'] == 0
+        assert none['remote_fetches'] >= tiny['remote_fetches'] >= out['remote_fetches']
     np.save(os.path.join(tmp, 'fetch%d.npy' % rank), np.array([out['remote_fetches']]))
     dist.barrier()
     dist.destroy_process_group()
