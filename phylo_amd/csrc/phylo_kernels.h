@@ -2066,69 +2066,82 @@ __device__ __forceinline__ void pk_twist_choose_body(const pk_twist_args& ta, do
     }
     const unsigned long long who = __ballot(crosses);
     const int jsel = who ? __shfl(cand, __ffsll((long long)who) - 1, 64) : J - 1;
-    if (lane != 0) return;
+    // From here on the WHOLE wave works (until round 3 lane 0 walked through some forty dependent loads and thirty-two stores
+    // alone: 17 us per rank event for 630 instructions): lane i loads what belongs to root slot i / history entry i / matrix
+    // element i, the sums of the contract are then formed in their order from registers (readlane: the indices are uniform),
+    // identically on every lane, and the lanes write their own pieces.
     double ssum = 0.0;
-    for (int j = 0; j < J; ++j) ssum = ssum + w[j];
+    for (int j = 0; j < J; ++j) ssum = ssum + w[j];          // (one address per step: an LDS broadcast)
     const double logq = pot[jsel] - ((all_bad ? 0.0 : mx) + pm_log(ssum));
     const int t = jsel / M;
     int il = 0, rem = t;
     while (rem >= n - 1 - il) { rem -= n - 1 - il; ++il; }
     const int ir = il + 1 + rem;
-    ta.chosen[kg] = (double)jsel;
     const int32_t* ro = ta.roots_ad + (size_t)kg * N;
     const int32_t* co = ta.cnt_ad + (size_t)kg * N;
     const double* rl = ta.rootll_ad + (size_t)kg * N;
+    const bool slot = lane < n;                              // (n <= N <= 64)
+    const int c_i = slot ? co[lane] : 0, ro_i = slot ? ro[lane] : 0;
+    const double rl_i = slot ? rl[lane] : 0.0;
+    const double ldf_i = -a.ldf[c_i < a.ldf_n ? c_i : a.ldf_n];
+    const double b_l = ta.tw_b[((size_t)k * J + jsel) * 2], b_r = ta.tw_b[((size_t)k * J + jsel) * 2 + 1];
+    const bool hist = lane <= a.r;                           // (r <= N - 2)
+    const double hl_i = !hist ? 0.0 : (lane == a.r ? b_l : a.bl[(size_t)lane * a.Kloc + k]);
+    const double hr_i = !hist ? 0.0 : (lane == a.r ? b_r : a.br[(size_t)lane * a.Kloc + k]);
+    const double P_i = lane < 32 ? ta.tw_P[((size_t)k * J + jsel) * 32 + lane] : 0.0;
     double sum_rem = 0.0, fprior = 0.0;
     int vminus = 0;
     for (int i = n - 1; i >= 0; --i) {                       // remaining roots, descending slot order
         if (i == il || i == ir) continue;
-        const int c = co[i];
-        sum_rem = sum_rem + rl[i];
-        fprior = fprior + (-a.ldf[c < a.ldf_n ? c : a.ldf_n]);
+        const int c = __builtin_amdgcn_readlane(c_i, i);
+        sum_rem = sum_rem + pk_readlane(rl_i, i);
+        fprior = fprior + pk_readlane(ldf_i, i);
         vminus += c - (c == 1 ? 1 : 0);
     }
-    const int cnew = co[il] + co[ir];
+    const int cnew = __builtin_amdgcn_readlane(c_i, il) + __builtin_amdgcn_readlane(c_i, ir);
     fprior = fprior + (-a.ldf[cnew < a.ldf_n ? cnew : a.ldf_n]);
     vminus += cnew - (cnew == 1 ? 1 : 0);
-    const double b_l = ta.tw_b[((size_t)k * J + jsel) * 2], b_r = ta.tw_b[((size_t)k * J + jsel) * 2 + 1];
-    ta.bl_r[k] = b_l;
-    ta.br_r[k] = b_r;
     double lp = 0.0, rp = 0.0;
     for (int j = 0; j <= a.r; ++j) {
-        const double hl = (j == a.r) ? b_l : a.bl[(size_t)j * a.Kloc + k];
-        const double hr = (j == a.r) ? b_r : a.br[(size_t)j * a.Kloc + k];
-        lp = lp + ((-a.lam_l) * hl + a.loglam_l);
-        rp = rp + ((-a.lam_r) * hr + a.loglam_r);
+        lp = lp + ((-a.lam_l) * pk_readlane(hl_i, j) + a.loglam_l);
+        rp = rp + ((-a.lam_r) * pk_readlane(hr_i, j) + a.loglam_r);
     }
-    double* ax = a.aux + (size_t)k * PK_AUX;
-    ax[AUX_SUM_REM] = sum_rem;
-    ax[AUX_FPRIOR] = fprior;
-    ax[AUX_LPRIOR] = lp;
-    ax[AUX_RPRIOR] = rp;
-    ax[AUX_PAREN] = ((a.loglam_l - a.lam_l * b_l) + a.loglam_r) - a.lam_r * b_r;
-    ax[AUX_LOGV] = pm_log((double)vminus);
-    ax[AUX_Q] = logq;                                        // vncsmc.py:491 subtracts the normalised log-potential
-    a.child[k * 2] = ro[il];
-    a.child[k * 2 + 1] = ro[ir];
-    a.merges[((size_t)a.r * a.Kloc + k) * 2] = il;
-    a.merges[((size_t)a.r * a.Kloc + k) * 2 + 1] = ir;
-    const double* P = ta.tw_P + ((size_t)k * J + jsel) * 32;
-    for (int u = 0; u < 32; ++u) ta.Pmat_r[(size_t)k * 32 + u] = P[u];
+    if (lane < 32) ta.Pmat_r[(size_t)k * 32 + lane] = P_i;
+    if (lane == 0) {
+        ta.chosen[kg] = (double)jsel;
+        ta.bl_r[k] = b_l;
+        ta.br_r[k] = b_r;
+        double* ax = a.aux + (size_t)k * PK_AUX;
+        ax[AUX_SUM_REM] = sum_rem;
+        ax[AUX_FPRIOR] = fprior;
+        ax[AUX_LPRIOR] = lp;
+        ax[AUX_RPRIOR] = rp;
+        ax[AUX_PAREN] = ((a.loglam_l - a.lam_l * b_l) + a.loglam_r) - a.lam_r * b_r;
+        ax[AUX_LOGV] = pm_log((double)vminus);
+        ax[AUX_Q] = logq;                                    // vncsmc.py:491 subtracts the normalised log-potential
+        a.child[k * 2] = __builtin_amdgcn_readlane(ro_i, il);
+        a.child[k * 2 + 1] = __builtin_amdgcn_readlane(ro_i, ir);
+        a.merges[((size_t)a.r * a.Kloc + k) * 2] = il;
+        a.merges[((size_t)a.r * a.Kloc + k) * 2 + 1] = ir;
+    }
     if (ta.own_tables) {                                     // one GPU: my own new root table (pk_twist_tables otherwise)
-        int p = 0;
-        for (int i = n - 1; i >= 0; --i) {
-            if (i == il || i == ir) continue;
-            a.roots_new[(size_t)kg * N + p] = ro[i];
-            a.cnt_new[(size_t)kg * N + p] = co[i];
-            a.rootll_new[(size_t)kg * N + p] = rl[i];
-            if (a.pos_hist) a.pos_hist[(size_t)kg * N + i] = p;
-            ++p;
+        if (slot) {
+            const bool merged = lane == il || lane == ir;
+            const int p = (n - 1 - lane) - (il > lane ? 1 : 0) - (ir > lane ? 1 : 0);   // remaining roots in descending slot order
+            if (!merged) {
+                a.roots_new[(size_t)kg * N + p] = ro_i;
+                a.cnt_new[(size_t)kg * N + p] = c_i;
+                a.rootll_new[(size_t)kg * N + p] = rl_i;
+            }
+            if (a.pos_hist) a.pos_hist[(size_t)kg * N + lane] = merged ? -1 : p;
         }
-        if (a.pos_hist) { a.pos_hist[(size_t)kg * N + il] = -1; a.pos_hist[(size_t)kg * N + ir] = -1; }
-        a.roots_new[(size_t)kg * N + p] = N + a.r * a.K + kg;
-        a.cnt_new[(size_t)kg * N + p] = co[il] + co[ir];
+        if (lane == 0) {
+            a.roots_new[(size_t)kg * N + (n - 2)] = N + a.r * a.K + kg;
+            a.cnt_new[(size_t)kg * N + (n - 2)] = cnew;
+        }
     }
 }
+
 __global__ __launch_bounds__(64) void pk_twist_choose(const pk_twist_args ta) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (ta.J <= PK_TWIST_LDS_J) pk_twist_choose_body(ta, reinterpret_cast<double*>(smem));
