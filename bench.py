@@ -79,7 +79,7 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true', help='skip the 10-seed comparison with the C oracle')
     p.add_argument('--no-vi-step', action='store_true', help='skip the timing of the VI training steps (SURVEY 8f.1) appended to the line')
-    p.add_argument('--min-timed-ms', type=float, default=100.0, help='repeat the K timed steps until this much time is covered')
+    p.add_argument('--min-timed-ms', type=float, default=2000.0, help='repeat the K timed steps until this much time is covered (the K steps alone last a few ms)')
     p.add_argument('--one-launch', action='store_true', help='single sweeps (t_sweep) in the one-launch form (phylo_persist.h)')
     p.add_argument('--cpu-seconds', type=float, default=12.0, help='target CPU-baseline duration')
     return p.parse_args()
@@ -374,7 +374,7 @@ def main():
         reps_dt.append(gmax(time.perf_counter() - t0) / inner)      # max over ranks (every rank takes the same decision below)
         if sum(reps_dt) * 1e3 >= a.min_timed_ms and len(reps_dt) >= 3:
             break
-        if len(reps_dt) >= 400:
+        if len(reps_dt) >= 4000:
             break
     dt = float(np.median(reps_dt))
     if batch > 1:
