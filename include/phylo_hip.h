@@ -211,6 +211,19 @@ int phylo_sweep_node(phylo_ctx* ctx, int r, int k, double* out_Sx4);
 int phylo_sweep_backward(phylo_ctx* ctx, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q,
                          phylo_stats* perf);
 
+/* The host half of a VI training step in the library (reference: optimizer.minimize(self.cost), vcsmc.py:488-491; the NumPy
+ * statement of the same formulas is phylo_amd/train.py).  Variables packed as a_l[N-1] | a_r[N-1] | y_q[16] | y_station[4] (the
+ * reference's 'left_branches_param', 'right_branches_param', 'Qmatrix', 'Stationary_probs': log-rates, vcsmc.py:119-124).
+ * phylo_vi_gradients: model from the variables (vcsmc.py:133-148; jc != 0: the JC69 constants) -> phylo_set_model -> sweep with
+ * PHYLO_KEEP_GRAPH on the context's leaves -> phylo_sweep_backward -> chain rules; grads = d logZ / d variables, packed alike
+ * (zeros for y_q, y_station under JC69).  fwd / bwd (may be NULL): phylo_sweep_fetch's and phylo_sweep_backward's stats.
+ * phylo_vi_apply: kind 0 tf.train.GradientDescentOptimizer (var += lr d logZ / d var), 1 tf.train.AdamOptimizer (TF 1.15
+ * defaults are beta1 0.9, beta2 0.999, eps 1e-8; t, m, v: its state, m and v packed like the variables, zero at the start). */
+int phylo_vi_gradients(phylo_ctx* ctx, uint64_t seed, uint32_t flags, int M, int jc, const double* vars, double* logZ, double* grads,
+                       phylo_stats* fwd, phylo_stats* bwd);
+int phylo_vi_apply(int n_taxa, int jc, double* vars, const double* grads, int kind, double lr, double beta1, double beta2, double eps,
+                   int64_t* t, double* m, double* v);
+
 /* Diagnostics of the one-launch sweep: with PHYLO_PERSIST_STAMPS=1 in the environment when the context is created,
  * workgroup 0 stamps s_memrealtime (100 MHz ticks) at its phase boundaries; out receives [N][16] values (rows 0..N-2: rank
  * events; row N-1: prologue).  No effect on results; not for timed runs. */

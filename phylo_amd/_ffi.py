@@ -30,6 +30,7 @@ EXPORTS = [
     "phylo_sweep_async", "phylo_sweep_batch_async", "phylo_sweep_batch_begin", "phylo_sweep_fetch_logz", "phylo_sweep_begin", "phylo_sweep_step", "phylo_sweep_step_a", "phylo_sweep_step_group", "phylo_sweep_finish", "phylo_sweep_fetch",
     "phylo_synchronize", "phylo_sweep_node", "phylo_sweep_backward",
     "phylo_math_probe", "phylo_debug_stamps", "phylo_debug_reverse_lists", "phylo_debug_device_lists", "phylo_debug_device_lists_of", "phylo_debug_remote_cache",
+    "phylo_vi_gradients", "phylo_vi_apply",
     "phylo_site_tile", "phylo_set_site_tile", "phylo_get_site_tile",
     "phylo_comm_unique_id", "phylo_comm_init", "phylo_comm_share", "phylo_comm_allgather", "phylo_comm_max", "phylo_comm_barrier",
     "phylo_comm_exchange_kind",
@@ -111,6 +112,21 @@ def _lists_dict(lists, meta, R, K):
     out["rank_chunk0"] = meta[6 + (R + 1):6 + 2 * (R + 1)].copy()
     out["ev_slow0"] = meta[6 + 2 * (R + 1):6 + 3 * (R + 1)].copy()
     return out
+
+
+def vi_apply(N, jc, packed_vars, packed_grads, kind, lr, beta1=0.9, beta2=0.999, eps=1e-8, state=None):
+    """phylo_vi_apply: the optimiser update on the packed variables IN PLACE (kind 0 gradient descent, 1 Adam with state =
+    {'t': int, 'm': array, 'v': array}, updated in place too)."""
+    lib = load()
+    t = C.c_int64(0 if state is None else int(state['t']))
+    m = None if state is None else state['m']
+    v = None if state is None else state['v']
+    rc = lib.phylo_vi_apply(C.c_int(N), C.c_int(int(jc)), _ptr(packed_vars), _ptr(packed_grads), C.c_int(kind), C.c_double(lr),
+                            C.c_double(beta1), C.c_double(beta2), C.c_double(eps), C.byref(t), _ptr(m), _ptr(v))
+    if rc:
+        raise PhyloError(rc, lib.phylo_last_error(None).decode())
+    if state is not None:
+        state['t'] = t.value
 
 
 def device_count():
@@ -302,6 +318,16 @@ class Context:
         out['backward_lists'] = 'device' if st.merge_launches else 'host'   # who built them (phylo_revlists_dev.h / phylo_revlists.h)
         out['backward_launches'] = st.n_launches
         return out
+
+    def vi_gradients(self, seed, flags, M, jc, packed_vars):
+        """The gradient half of a VI training step in the library (phylo_vi_gradients): packed_vars = a_l | a_r | y_q | y_station.
+        Returns (logZ, grads packed alike, forward stats, backward stats)."""
+        vars_ = _f64(packed_vars)
+        grads = np.empty_like(vars_)
+        z, fwd, bwd = C.c_double(), Stats(), Stats()
+        self._check(self._lib.phylo_vi_gradients(self._h, C.c_uint64(seed), C.c_uint32(flags), C.c_int(M), C.c_int(int(jc)), _ptr(vars_),
+                                                 C.byref(z), _ptr(grads), C.byref(fwd), C.byref(bwd)))
+        return z.value, grads, fwd, bwd
 
     def debug_device_lists(self, ancestors=None, child=None):
         """The reverse pass's integer lists as the device kernels build them from the last (lazy, KEEP_GRAPH, plain proposal) sweep,

@@ -20,6 +20,7 @@
 #include "phylo_persist.h"
 #include "phylo_grad.h"
 #include "phylo_revlists_dev.h"
+#include "phylo_train.h"
 
 namespace {
 
@@ -198,6 +199,7 @@ struct phylo_ctx {
     size_t h_csr_cap = 0;                // int32 elements
     hipEvent_t ev_gcopy = nullptr;
     std::vector<int32_t> h_cur;          // scratch of the counting sorts
+    std::vector<double> h_vi_lam;        // phylo_vi_gradients: the rates of the step (phylo_set_model copies them)
     std::vector<int32_t> h_xlists;       // ... of its twisted part
     hipEvent_t evb0 = nullptr, evb1 = nullptr, ev_model = nullptr;
     // reverse pass: the adopted nodes' chain runs on gstream beside the coefficient chain on `stream`; ev_coeff[r]: C of rank event r done
@@ -2339,6 +2341,37 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         perf->merge_ms = host_ms;                          // here: host time of the integer lists (built, or waited for: device lists)
         perf->merge_launches = dev_lists ? 1 : 0;          // here: 1 = the lists were built by kernels (phylo_revlists_dev.h)
     }
+    return PHYLO_OK;
+}
+
+// ---- a VI training step's host half in C++ (phylo_train.h): variables -> model -> sweep + reverse pass -> gradients of the variables
+int phylo_vi_gradients(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, int jc, const double* vars, double* logZ, double* grads,
+                       phylo_stats* fwd, phylo_stats* bwd) {
+    CHK(bind(c));
+    if (!vars || !grads) return fail(c, PHYLO_EINVAL, "phylo_vi_gradients: NULL argument");
+    const int R = c->N - 1;
+    double Q[16], pi[4];
+    std::vector<double>& lam = c->h_vi_lam;
+    lam.resize((size_t)2 * R);
+    for (int r = 0; r < 2 * R; ++r) lam[r] = std::exp(vars[r]);
+    if (jc) pt_jc_Q(Q); else pt_get_Q(vars + 2 * R, Q);
+    pt_get_pi(vars + 2 * R + 16, pi);
+    CHK(phylo_set_model(c, Q, pi, lam.data(), lam.data() + R, jc));
+    CHK(phylo_sweep_async(c, seed, flags | PHYLO_KEEP_GRAPH, M));
+    double raw[2 * 64 + 20];
+    if (R > 64) return fail(c, PHYLO_EINVAL, "phylo_vi_gradients: at most 65 taxa");
+    CHK(phylo_sweep_backward(c, raw, raw + R, raw + 2 * R, raw + 2 * R + 4, bwd));
+    CHK(phylo_sweep_fetch(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, logZ, fwd));
+    pt_chain_rules(R, jc, Q, pi, lam.data(), lam.data() + R, raw, raw + R, raw + 2 * R, raw + 2 * R + 4, grads);
+    return PHYLO_OK;
+}
+
+int phylo_vi_apply(int n_taxa, int jc, double* vars, const double* grads, int kind, double lr, double beta1, double beta2, double eps, int64_t* t,
+                   double* m, double* v) {
+    if (n_taxa < 2 || !vars || !grads || (kind != 0 && (!t || !m || !v)))
+        return fail(nullptr, PHYLO_EINVAL, "phylo_vi_apply: bad arguments");
+    const int R = n_taxa - 1;
+    pt_apply(jc ? 2 * R : 2 * R + 20, vars, grads, kind, lr, beta1, beta2, eps, t, m, v);
     return PHYLO_OK;
 }
 

@@ -30,6 +30,23 @@ class Variables:
     def names(self):
         return ('a_l', 'a_r') if self.jc else ('a_l', 'a_r', 'y_q', 'y_station')
 
+    def pack(self):
+        """a_l | a_r | y_q | y_station, the layout of phylo_vi_gradients / phylo_vi_apply"""
+        return np.concatenate([self.a_l, self.a_r, np.asarray(self.y_q, dtype=np.float64).reshape(-1), self.y_station])
+
+    def unpack(self, p):
+        R = self.a_l.shape[0]
+        self.a_l, self.a_r = p[:R].copy(), p[R:2 * R].copy()
+        if not self.jc:
+            self.y_q, self.y_station = p[2 * R:2 * R + 16].reshape(4, 4).copy(), p[2 * R + 16:2 * R + 20].copy()
+
+    def unpack_grads(self, g):
+        R = self.a_l.shape[0]
+        out = {'a_l': g[:R], 'a_r': g[R:2 * R]}
+        if not self.jc:
+            out['y_q'], out['y_station'] = g[2 * R:2 * R + 16].reshape(4, 4), g[2 * R + 16:2 * R + 20]
+        return out
+
     def evaluate(self):
         """(Q, pi[1,A], lam_l, lam_r) as the graph evaluates them."""
         Q = model.jc_Q(self.y_q.shape[0]) if self.jc else model.get_Q(self.y_q)
@@ -88,6 +105,12 @@ class GradientDescent:
         for name in v.names():
             setattr(v, name, getattr(v, name) + self.lr * grads_logZ[name])
 
+    def apply_packed(self, v, packed_grads):
+        """the same update by the library (phylo_vi_apply) on the packed variables"""
+        p = v.pack()
+        _ffi.vi_apply(v.a_l.shape[0] + 1, v.jc, p, packed_grads, 0, self.lr)
+        v.unpack(p)
+
 
 class Adam:
     """tf.train.AdamOptimizer (TF 1.15 defaults beta1 .9, beta2 .999, epsilon 1e-8):
@@ -111,6 +134,16 @@ class Adam:
             self.m[name], self.v[name] = m, s
             setattr(v, name, getattr(v, name) - lr_t * m / (np.sqrt(s) + self.eps))
 
+    def apply_packed(self, v, packed_grads):
+        """the same update by the library (phylo_vi_apply) on the packed variables; its state lives in self.state (an optimiser
+        object is driven through ONE of the two forms)"""
+        p = v.pack()
+        if getattr(self, 'state', None) is None:
+            self.state = {'t': 0, 'm': np.zeros_like(p), 'v': np.zeros_like(p)}
+        _ffi.vi_apply(v.a_l.shape[0] + 1, v.jc, p, packed_grads, 1, self.lr, self.b1, self.b2, self.eps, self.state)
+        self.t = self.state['t']
+        v.unpack(p)
+
 
 def make_optimizer(name, learning_rate):
     """runner.py:30-33: 'Adam' selects Adam, anything else plain gradient descent (vcsmc.py:488-491)."""
@@ -120,9 +153,13 @@ def make_optimizer(name, learning_rate):
 class Trainer:
     """One device context sized for a minibatch of sites; `step` = sweep + reverse pass + update."""
 
-    def __init__(self, genome_NxSxA, K, variables, optimizer, batch_sites, device=0, flags=_ffi.FLAGS_DEFAULT, nested=False, M=1):
+    def __init__(self, genome_NxSxA, K, variables, optimizer, batch_sites, device=0, flags=_ffi.FLAGS_DEFAULT, nested=False, M=1,
+                 native=True):
         """nested: the twisted proposal of vncsmc.py with M sub-samples per pair; its look-ahead potentials are differentiated
-        like everything else (vncsmc.py:379-416 has no stop_gradient)."""
+        like everything else (vncsmc.py:379-416 has no stop_gradient).  native: the host half of a step (model from the
+        variables, chain rules, optimiser update) runs in the library (phylo_vi_gradients / phylo_vi_apply) instead of the NumPy
+        statements of this module (~60 small array operations, 65 us of a 0.9 ms step); same formulas."""
+        self.native = bool(native)
         self.genome = np.asarray(genome_NxSxA, dtype=np.float64)
         self.v, self.opt = variables, optimizer
         self.flags = (flags | _ffi.KEEP_GRAPH) & ~_ffi.TWISTING
@@ -151,18 +188,39 @@ class Trainer:
         raw['forward_ms'] = out['stats']['sweep_ms']
         return out['logZ'], chain_rules(self.v, Q, pi, lam_l, lam_r, raw), raw
 
+    def _gradients_native(self, sites, seed):
+        """gradients() through phylo_vi_gradients: (logZ, grads dict, raw timings, grads packed)"""
+        sites = np.asarray(sites)
+        if self._sites is None or not np.array_equal(sites, self._sites):
+            self.ctx.set_leaves(self.genome[:, sites, :])
+            self._sites = sites.copy()
+        logZ, g, fwd, bwd = self.ctx.vi_gradients(int(seed), self.flags, self.M, self.v.jc, self.v.pack())
+        raw = {'forward_ms': fwd.sweep_ms, 'backward_ms': bwd.sweep_ms, 'backward_host_ms': bwd.merge_ms,
+               'backward_lists': 'device' if bwd.merge_launches else 'host', 'backward_launches': bwd.n_launches}
+        return logZ, self.v.unpack_grads(g), raw, g
+
     def step(self, sites, seed, more_seeds=(), comm_ctx=None):
         """_, cost = sess.run([self.optimizer, self.cost], feed_dict={self.core: data_batch})  (vcsmc.py:534).
         Data-parallel training: more_seeds = further independent particle systems swept by this process for the same step,
         comm_ctx = a context that has joined the ranks (every rank sweeps its own systems with its own seeds); the optimiser takes
         ONE step on the mean gradient of all of them (mean_of_samples), the same step on every rank."""
-        logZ, grads, raw = self.gradients(sites, seed)
+        if self.native:
+            logZ, grads, raw, packed = self._gradients_native(sites, seed)
+        else:
+            logZ, grads, raw = self.gradients(sites, seed)
         if more_seeds or comm_ctx is not None:
             samples = [(logZ, grads)]
             for s2 in more_seeds:
-                z2, g2, raw = self.gradients(sites, s2)
+                z2, g2, raw = (self._gradients_native(sites, s2)[:3] if self.native else self.gradients(sites, s2))
                 samples.append((z2, g2))
             logZ, grads = mean_of_samples(samples, comm_ctx)
-        self.opt.apply(self.v, grads)
+            if self.native:
+                packed = np.concatenate([np.asarray(grads[n], dtype=np.float64).reshape(-1) for n in ('a_l', 'a_r', 'y_q', 'y_station') if n in grads])
+        if self.native:
+            if packed.shape[0] < self.v.pack().shape[0]:     # (JC69: y_q and y_station are constants, their slots stay zero)
+                packed = np.concatenate([packed, np.zeros(20)])
+            self.opt.apply_packed(self.v, packed)
+        else:
+            self.opt.apply(self.v, grads)
         self.last = {'logZ': logZ, 'grads': grads, 'raw': raw}
         return -logZ

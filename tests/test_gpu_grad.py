@@ -214,6 +214,28 @@ def test_trainer_gradients_match_oracle_chain_rules():
         assert np.max(np.abs(grads[mine] - ref[theirs])) < 1e-9 * scale, mine
 
 
+@pytest.mark.parametrize("nested,jc,opt", [(False, False, 'Adam'), (False, True, 'GD'), (True, False, 'Adam')])
+def test_training_step_in_the_library_equals_the_numpy_step(nested, jc, opt):
+    """Trainer.step with the host half in the library (phylo_vi_gradients / phylo_vi_apply: model from the variables, chain rules,
+    optimiser) against the NumPy statements of phylo_amd/train.py: the same variables after four steps (exp of the host's libm
+    against NumPy's: a last-bit difference in Q would show as 1e-16 in the gradients, not as a different genealogy here)."""
+    from phylo_amd import train as T
+    genome = load_dataset('primate_data_wang')['genome'][:, :96]
+    N = genome.shape[0]
+    out = {}
+    for native in (True, False):
+        v = T.Variables(N, np.log(10.0), jc)
+        tr = T.Trainer(genome, 48, v, T.make_optimizer(opt if opt == 'Adam' else 'GradientDescentOptimizer', 0.02), 96, nested=nested, M=2,
+                       native=native)
+        costs = [tr.step(np.arange(96), seed=30 + i) for i in range(4)]
+        out[native] = (costs, {n: np.array(getattr(v, n)) for n in v.names()}, tr.last['raw'])
+        tr.close()
+    assert out[True][2]['backward_lists'] == out[False][2]['backward_lists']
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-12)
+    for n in out[True][1]:
+        np.testing.assert_allclose(out[True][1][n], out[False][1][n], rtol=1e-10, atol=1e-13)
+
+
 def test_full_size_gradient_is_the_directional_derivative():
     """BASELINE size (primate, K = 2048, all 898 sites): central difference of the forward sweep along the
     gradient direction, same seed (the resampling outcomes must not change for the difference to be smooth)."""
