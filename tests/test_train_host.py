@@ -1,6 +1,7 @@
 """Host side of the VI training step (phylo_amd/train.py): parameterisation, chain rules, optimiser update rules.
 CPU only; the device gradient itself is covered by tests/test_gpu_grad.py."""
 import numpy as np
+import pytest
 
 from oracle import cpu_grad as G
 from phylo_amd import model
@@ -80,3 +81,21 @@ def test_batch_slices_partition_and_rng_sequence():
     assert slices[1] == random.sample(rest, b)                             # second draw: over the set-difference order
     assert [len(s) for s in VCSMC.batch_slices(None, data, 1000)] == [898]
     assert [len(s) for s in VCSMC.batch_slices(None, np.zeros((1, 2, 512, 4)), 256)] == [256, 256]
+
+
+@pytest.mark.parametrize("jc", [False, True])
+@pytest.mark.parametrize("name", ['Adam', 'GradientDescentOptimizer'])
+def test_library_optimisers_equal_the_numpy_ones_bit_for_bit(jc, name):
+    """phylo_vi_apply (phylo_train.h; no GPU needed) against GradientDescent / Adam of phylo_amd/train.py over five steps."""
+    rng = np.random.default_rng(5)
+    v1, v2 = T.Variables(7, np.log(10.0), jc), T.Variables(7, np.log(10.0), jc)
+    o1, o2 = T.make_optimizer(name, 0.05), T.make_optimizer(name, 0.05)
+    for _ in range(5):
+        g = {'a_l': rng.normal(size=6), 'a_r': rng.normal(size=6)}
+        if not jc:
+            g['y_q'], g['y_station'] = rng.normal(size=(4, 4)), rng.normal(size=4)
+        packed = np.concatenate([g['a_l'], g['a_r'], g.get('y_q', np.zeros((4, 4))).reshape(-1), g.get('y_station', np.zeros(4))])
+        o1.apply(v1, g)
+        o2.apply_packed(v2, packed)
+    for n in ('a_l', 'a_r', 'y_q', 'y_station'):
+        assert np.array_equal(np.asarray(getattr(v1, n)).view(np.uint64), np.asarray(getattr(v2, n)).view(np.uint64)), n
