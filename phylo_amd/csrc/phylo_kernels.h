@@ -975,32 +975,44 @@ __device__ __forceinline__ void pk_book_packed(const pk_rank_args& a, int kg, bo
         }
     }
     __syncthreads();
-    if (sl == 0 && local) {                           // sequential sums, LDS operands only (one lane per particle)
-        double sum_rem = 0.0, fprior = 0.0;
-        int vminus = 0;
+    if (local) {
+        // The sequential sums of the contract, LDS operands only.  Four independent chains -- the remaining roots' log-likelihoods,
+        // their leaf-count priors, the left and the right branch-history priors with THIS rank's rate (quirk Q3) -- run on four
+        // lanes of the particle's group through ONE loop, acc += a x[j] + b with the chain's own (x, a, b, length): a = 1, b = 0
+        // and a = -1, b = 0 reproduce `acc + x` and `acc + (-x)` bit for bit.  (One lane used to walk all four in turn: half of
+        // this kernel's instructions, for 4 of 64 lanes.)
+        const double* src = sl == 0 ? L.ord_ll : sl == 1 ? L.ord_ldf : sl == 2 ? L.hbl : L.hbr;
+        const int cnt = sl == 0 ? n - 2 : sl == 1 ? n - 1 : sl < 4 ? a.r + 1 : 0;
+        const double ca = sl == 0 ? 1.0 : sl == 1 ? -1.0 : sl == 2 ? -a.lam_l : -a.lam_r;
+        const double cb = sl == 2 ? a.loglam_l : sl == 3 ? a.loglam_r : 0.0;
+        const int trips = n - 1 > a.r + 1 ? n - 1 : a.r + 1;
+        double acc = 0.0;
         #pragma unroll 1
-        for (int p = 0; p < n - 2; ++p) sum_rem = sum_rem + L.ord_ll[p];
+        for (int j = 0; j < trips; ++j)
+            if (j < cnt) acc = acc + (ca * src[j] + cb);
+        int vminus = 0;                                   // integers: any order
         #pragma unroll 1
-        for (int p = 0; p < n - 1; ++p) {
+        for (int p = sl; p < n - 1; p += LP) {
             const int c = L.ord_cnt[p];
-            fprior = fprior + (-L.ord_ldf[p]);
             vminus += c - (c == 1 ? 1 : 0);
         }
-        double lp = 0.0, rp = 0.0;                    // history rows 0..r with THIS rank's rate (quirk Q3)
-        #pragma unroll 1
-        for (int j = 0; j <= a.r; ++j) {
-            lp = lp + ((-a.lam_l) * L.hbl[j] + a.loglam_l);
-            rp = rp + ((-a.lam_r) * L.hbr[j] + a.loglam_r);
-        }
-        const double b_l = L.hbl[a.r], b_r = L.hbr[a.r];
+#pragma unroll
+        for (int off = 1; off < LP; off <<= 1) vminus += __shfl_xor(vminus, off, 64);
         const double q = 1.0 / ((double)((n - 1) * n) / 2.0);      // 1 / ncr(n, 2), vcsmc.py:298
-        L.aux[AUX_SUM_REM] = sum_rem;
-        L.aux[AUX_FPRIOR] = fprior;
-        L.aux[AUX_LPRIOR] = lp;
-        L.aux[AUX_RPRIOR] = rp;
-        L.aux[AUX_PAREN] = ((a.loglam_l - a.lam_l * b_l) + a.loglam_r) - a.lam_r * b_r;
-        L.aux[AUX_LOGV] = pm_log((double)vminus);
-        L.aux[AUX_Q] = (a.flags & 1u) ? q : pm_log(q);
+        const double lg = pm_log(sl == 0 ? (double)vminus : q);    // lane 0: log v-, lane 1: log q (one instruction stream)
+        if (sl == 0) {
+            const double b_l = L.hbl[a.r], b_r = L.hbr[a.r];
+            L.aux[AUX_SUM_REM] = acc;
+            L.aux[AUX_PAREN] = ((a.loglam_l - a.lam_l * b_l) + a.loglam_r) - a.lam_r * b_r;
+            L.aux[AUX_LOGV] = lg;
+        } else if (sl == 1) {
+            L.aux[AUX_FPRIOR] = acc;
+            L.aux[AUX_Q] = (a.flags & 1u) ? q : lg;
+        } else if (sl == 2) {
+            L.aux[AUX_LPRIOR] = acc;
+        } else if (sl == 3) {
+            L.aux[AUX_RPRIOR] = acc;
+        }
     }
     __syncthreads();
 }
