@@ -27,6 +27,14 @@ def lib():
             build()
         _LIB = C.CDLL(path)
         _LIB.ora_log_zsmc.restype = C.c_double
+        # OpenMP sizes its team by the host's hardware threads; a container or GPU box grants far fewer (16 there), and an
+        # oversubscribed team makes every small parallel region cost milliseconds.  Callers may still set_threads().
+        if "OMP_NUM_THREADS" not in os.environ:
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            _LIB.ora_set_threads(max(1, min(avail, 16)))
     return _LIB
 
 
