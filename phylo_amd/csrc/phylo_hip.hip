@@ -51,7 +51,7 @@ struct env_switches {
     bool eager_nodes = false, rehearse_sharded = false, replicated_book = false, fuse_scan = false,
          book_one_per_wave = false, merge_pair_form = false, no_leaf_codes = false, one_launch = false,
          persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, rev_host_lists = false, no_remote_cache = false, no_spin_wait = false,
-         no_p2p = false;
+         no_p2p = false, book_lp16 = false;
     int persist_wgs = 0;                 // PHYLO_PERSIST_WGS: resident workgroups of the one-launch sweep (0 = default)
     unsigned long long p2p_wait_ticks = PK_P2P_WAIT_TICKS;   // PHYLO_P2P_WAIT_S: bound of a flag wait of the device-side exchange
     size_t p2p_copy_words = 65536;       // PHYLO_P2P_COPY_WORDS: exchanges beyond this many doubles copy with many workgroups (tests lower it)
@@ -64,6 +64,7 @@ struct env_switches {
         replicated_book = getenv("PHYLO_REPLICATED_BOOK") != nullptr;
         fuse_scan = getenv("PHYLO_FUSE_SCAN") != nullptr;
         book_one_per_wave = getenv("PHYLO_BOOK_ONE_PER_WAVE") != nullptr;
+        book_lp16 = getenv("PHYLO_BOOK_LP16") != nullptr;
         merge_pair_form = getenv("PHYLO_MERGE_PAIR_FORM") != nullptr;
         no_leaf_codes = getenv("PHYLO_NO_LEAF_CODES") != nullptr;
         one_launch = getenv("PHYLO_ONE_LAUNCH") != nullptr;
@@ -1086,7 +1087,7 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     // one sweep alone on one GPU with lazy nodes: the adopted nodes are written in the bookkeeping launch (pk_rank_book_mat), found
     // by the resampling draws, which pk_sweep_prologue then leaves in d_rdraw.  Batched sweeps keep the separate launch (measured:
-    // 2.62e11 against 2.64e11 units/s with the grouped form of the combined launch: nothing to gain).
+    // 2.62e11 against 2.64e11 units/s with the grouped form of the combined launch in round 2; round 3, a launch set alone: 3.57e11 against 3.77e11).
     const bool book_mat = lazy && c->world == 1 && c->comm.transport == 0 && !fuse_scan && N <= 64 && S <= 4096 && G == 1 && Kl <= 8192 &&
                           !c->env.separate_materialise && !c->env.book_one_per_wave;
     // sharded with lazy nodes: each owner finds ITS adopted nodes the same way (O(Kloc Kg / 64) comparisons) instead of every rank
@@ -1482,7 +1483,12 @@ static int sweep_step_impl(phylo_ctx* c, int phase) {
             }
             c->run.local_book = local_book;
             const int nbook = local_book ? Kl : K;
-            if (N <= 16 && !c->env.book_one_per_wave)        // 4 particles per wave (PK_AUX + 2 = 10 <= 16 lanes)
+            // large launches (batched sweeps) are bound by instruction issue: 8 lanes per particle serve 8 particles with one
+            // instruction stream (3.52e11 -> 3.68e11 units/s for a launch set of 20 sweeps; 4 lanes: no further gain); small
+            // launches are latency chains and keep the shorter 16-lane form
+            if (N <= 16 && !c->env.book_one_per_wave && !c->env.book_lp16 && nbook >= 8192)
+                hipLaunchKernelGGL(pk_rank_book_packed<8>, dim3(cdiv(nbook, 8)), dim3(64), lds * 8, c->stream, b);
+            else if (N <= 16 && !c->env.book_one_per_wave)   // 4 particles per wave (PK_AUX + 2 = 10 <= 16 lanes)
                 hipLaunchKernelGGL(pk_rank_book_packed<16>, dim3(cdiv(nbook, 4)), dim3(64), lds * 4, c->stream, b);
             else if (N <= 32 && !c->env.book_one_per_wave)   // 2 particles per wave
                 hipLaunchKernelGGL(pk_rank_book_packed<32>, dim3(cdiv(nbook, 2)), dim3(64), lds * 2, c->stream, b);

@@ -1077,10 +1077,13 @@ __global__ __launch_bounds__(64) void pk_rank_book_packed(const pk_rank_args a) 
     const pk_book_lds L = pk_book_carve(smem + (size_t)sub * pk_book_lds_bytes(a.N), a.N);
     const bool local = kg >= a.k0 && kg < a.k0 + a.Kloc;
     pk_book_packed<LP>(a, kg, local, L, sl, lane);
-    if (local && sl < PK_AUX + 2) {
+    if (local) {
         const int k = kg - a.k0;
-        if (sl < PK_AUX) a.aux[(size_t)k * PK_AUX + sl] = L.aux[sl];
-        else a.child[k * 2 + (sl - PK_AUX)] = L.misc[sl - PK_AUX];
+#pragma unroll
+        for (int t = sl; t < PK_AUX + 2; t += LP) {     // (one trip for LP >= 16)
+            if (t < PK_AUX) a.aux[(size_t)k * PK_AUX + t] = L.aux[t];
+            else a.child[k * 2 + (t - PK_AUX)] = L.misc[t - PK_AUX];
+        }
     }
     if (a.lazy && a.r > 0 && sl == 0) {
         const int anc = L.misc[3];
@@ -1117,6 +1120,7 @@ __global__ __launch_bounds__(64) void pk_all_marks(const pk_rank_args a) {
 
 // Write node (rho, kappa) into the pool: the same merge, row per thread, no likelihood.  Called by ONE wave.
 __device__ __forceinline__ const double* pk_node_ptr(const pk_rank_args& a, int id);
+template <int U = 4>
 __device__ __forceinline__ void pk_materialize_node(const pk_rank_args& a, int rho, int kappa, int lane, int nthreads,
                                                     int s_begin, int s_end) {
     const int k = kappa - a.k0;
@@ -1128,12 +1132,23 @@ __device__ __forceinline__ void pk_materialize_node(const pk_rank_args& a, int r
 #pragma unroll
     for (int j = 0; j < 16; ++j) { Pl[j] = P[j]; Pr[j] = P[16 + j]; }
     double* out = a.pool + ((size_t)rho * a.Kloc + k) * (size_t)a.S * 4;
-    for (int s = s_begin + lane; s < s_end; s += nthreads) {
-        double Lv[4], Rv[4], o[4];
-        pk_load4(Lp + (size_t)s * 4, Lv);
-        pk_load4(Rp + (size_t)s * 4, Rv);
-        pk_merge_site(Lv, Rv, Pl, Pr, o);
-        pk_store4(out + (size_t)s * 4, o);
+    // U rows per thread in flight (four in the kernels that only write nodes): the rows are independent, and a node of a few
+    // hundred rows is otherwise one dependent load -> store round trip after the other (a short alignment is then read in ONE
+    // round trip).  The kernels that also do the bookkeeping have no registers to spare for it (U = 1).
+    for (int s = s_begin + lane; s < s_end; s += U * nthreads) {
+        double Lv[U][4], Rv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int su = s + u * nthreads < s_end ? s + u * nthreads : s;      // (a row past the end re-reads this thread's first)
+            pk_load4(Lp + (size_t)su * 4, Lv[u]);
+            pk_load4(Rp + (size_t)su * 4, Rv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double o[4];
+            pk_merge_site(Lv[u], Rv[u], Pl, Pr, o);
+            if (s + u * nthreads < s_end) pk_store4(out + (size_t)(s + u * nthreads) * 4, o);
+        }
     }
 }
 
@@ -1208,7 +1223,7 @@ __device__ __forceinline__ void pk_mat_by_thresholds(const pk_rank_args& a, int 
         hit |= (unsigned int)(t >= lo) & (unsigned int)(t < hi);
     }
     if (!__syncthreads_or((int)hit)) return;
-    pk_materialize_node(a, a.r - 1, kg, tid, PK_COLS, 0, a.S);
+    pk_materialize_node<1>(a, a.r - 1, kg, tid, PK_COLS, 0, a.S);
     if (tid == 0) a.mark[(size_t)(a.r - 1) * a.K + kg] = 1u;
 }
 __device__ __forceinline__ void pk_mat_by_thresholds_grouped(const pk_rank_args& a, int k0) {   // particles k0 .. k0 + 63, one group
@@ -1248,7 +1263,7 @@ __device__ __forceinline__ void pk_mat_by_thresholds_grouped(const pk_rank_args&
     while (todo) {                                        // workgroup-uniform
         const int j = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        pk_materialize_node(a, a.r - 1, k0 + j, tid, PK_COLS, 0, a.S);
+        pk_materialize_node<1>(a, a.r - 1, k0 + j, tid, PK_COLS, 0, a.S);
         if (tid == 0) a.mark[(size_t)(a.r - 1) * a.K + k0 + j] = 1u;
     }
 }
