@@ -51,7 +51,7 @@ struct env_switches {
     bool eager_nodes = false, rehearse_sharded = false, replicated_book = false, fuse_scan = false,
          book_one_per_wave = false, merge_pair_form = false, no_leaf_codes = false, one_launch = false,
          persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, rev_host_lists = false, no_remote_cache = false, no_spin_wait = false,
-         no_p2p = false, book_lp16 = false;
+         no_p2p = false, book_lp16 = false, no_sorted_draws = false;
     int persist_wgs = 0;                 // PHYLO_PERSIST_WGS: resident workgroups of the one-launch sweep (0 = default)
     unsigned long long p2p_wait_ticks = PK_P2P_WAIT_TICKS;   // PHYLO_P2P_WAIT_S: bound of a flag wait of the device-side exchange
     size_t p2p_copy_words = 65536;       // PHYLO_P2P_COPY_WORDS: exchanges beyond this many doubles copy with many workgroups (tests lower it)
@@ -65,6 +65,7 @@ struct env_switches {
         fuse_scan = getenv("PHYLO_FUSE_SCAN") != nullptr;
         book_one_per_wave = getenv("PHYLO_BOOK_ONE_PER_WAVE") != nullptr;
         book_lp16 = getenv("PHYLO_BOOK_LP16") != nullptr;
+        no_sorted_draws = getenv("PHYLO_NO_SORTED_DRAWS") != nullptr;
         merge_pair_form = getenv("PHYLO_MERGE_PAIR_FORM") != nullptr;
         no_leaf_codes = getenv("PHYLO_NO_LEAF_CODES") != nullptr;
         one_launch = getenv("PHYLO_ONE_LAUNCH") != nullptr;
@@ -1111,11 +1112,16 @@ static int sweep_begin_impl(phylo_ctx* c, uint64_t seed, uint32_t flags, int M, 
         pa.roots = t_roots; pa.cnt = t_cnt; pa.rootll = t_rootll; pa.nodell = c->d_nodell; pa.K = K; pa.N = N;
         pa.mark = lazy ? c->d_mark : (unsigned int*)nullptr;
         pa.mark_words = lazy ? (unsigned int)mark_words : 0u;
-        pa.draw_blocks = cdiv(2L * R * Kl, 64);
-        pa.init_blocks = cdiv((long)K * N, 256);
-        pa.mark_blocks = lazy ? cdiv((long)mark_words, 256) : 0;
-        const int rdraw_blocks = want_rdraw ? cdiv((long)(R - 1) * K, 64) : 0;
-        hipLaunchKernelGGL(pk_sweep_prologue, dim3(pa.draw_blocks + pa.init_blocks + pa.mark_blocks + rdraw_blocks), dim3(64), 0, c->stream, pa);
+        // large launches (batched sweeps): the matrices sorted by Pade order inside workgroups of 1024 (pk_sweep_draws_sorted)
+        const bool sorted = !c->jc && 2L * R * Kl >= 262144 && !c->env.no_sorted_draws;
+        const int NT = sorted ? 256 : 64;
+        pa.draw_blocks = sorted ? cdiv(2L * R * Kl, PK_DRAW_ITEMS) : cdiv(2L * R * Kl, 64);
+        pa.init_blocks = cdiv((long)K * N, 4 * NT);
+        pa.mark_blocks = lazy ? cdiv((long)mark_words, 4 * NT) : 0;
+        const int rdraw_blocks = want_rdraw ? cdiv((long)(R - 1) * K, NT) : 0;
+        const dim3 pgrid(pa.draw_blocks + pa.init_blocks + pa.mark_blocks + rdraw_blocks);
+        if (sorted) hipLaunchKernelGGL(pk_sweep_prologue_sorted, pgrid, dim3(256), 0, c->stream, pa);
+        else hipLaunchKernelGGL(pk_sweep_prologue, pgrid, dim3(64), 0, c->stream, pa);
         CHK(launch_check(c, "pk_sweep_prologue"));
         launches += 1;
     } else {

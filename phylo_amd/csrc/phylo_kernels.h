@@ -91,6 +91,9 @@ __device__ __forceinline__ double pk_wave_tree_sum(double v) {
 typedef double pk_d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const pk_d2 pk_gd2c;
 typedef __attribute__((address_space(1))) pk_d2 pk_gd2;
+// LDS written by some lanes of a wave and read by others of the SAME wave: the LDS pipe serves a wave's instructions in
+// order, so only the compiler has to be kept from moving the reads up
+__device__ __forceinline__ void pk_wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ pk_d2 pk_gload2(const double* p) { return *(pk_gd2c*)p; }
 
 __device__ __forceinline__ void pk_load4(const double* __restrict__ p, double* v) {
@@ -192,13 +195,97 @@ struct pk_prologue_args {
     unsigned int mark_words;            // multiple of 4
     int draw_blocks, init_blocks, mark_blocks;   // then the blocks that fill rdraw
 };
-__global__ __launch_bounds__(64) void pk_sweep_prologue(const pk_prologue_args p) {
+// The draws of a LARGE launch (batched sweeps), sorted by the work they need.  pm_expm4 picks its Pade order per matrix from
+// ||Q b||_1; with one matrix per lane in index order nearly every wave holds all five orders and runs all five branches
+// (~2500 VALU instructions per wave, 70 % of the lanes needing order 5 only).  Here a workgroup of 256 threads takes
+// PK_DRAW_ITEMS matrices: pass 1 draws the branch lengths (one Philox evaluation serves both sides of a particle) and files
+// every matrix under an ESTIMATE of its order (b ||Q||_1 against the thresholds) in LDS; pass 2 walks the list so that a wave's
+// 64 matrices are of one class except where two classes meet.  pm_expm4 itself is unchanged and decides the order as before:
+// the estimate only schedules, it cannot change a bit.
+#define PK_DRAW_ITEMS 1024
+__device__ __forceinline__ void pk_sweep_draws_sorted(int wg, const pk_prologue_args& p) {
+    __shared__ double sb[PK_DRAW_ITEMS];
+    __shared__ unsigned short slist[PK_DRAW_ITEMS];
+    __shared__ int scount[8];
+    const int tid = threadIdx.x, NT = 256;
+    const int total = 2 * p.R * p.Kloc, base = wg * PK_DRAW_ITEMS;
+    if (tid < 8) scount[tid] = 0;
+    double q[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) q[j] = p.Q[j];
+    double qn = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double cs = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs = cs + (q[i * 4 + j] < 0.0 ? -q[i * 4 + j] : q[i * 4 + j]);
+        qn = cs > qn ? cs : qn;
+    }
+    __syncthreads();
+    int cls[PK_DRAW_ITEMS / 512][2], pos[PK_DRAW_ITEMS / 512][2];
+#pragma unroll
+    for (int u = 0; u < PK_DRAW_ITEMS / 512; ++u) {
+        const int pair = u * NT + tid, t0 = base + 2 * pair;        // (base is even: both sides of a particle in one workgroup)
+        cls[u][0] = cls[u][1] = -1;
+        if (t0 < total) {
+            const int i = t0 >> 1, r = i / p.Kloc, k = i - r * p.Kloc;
+            int kp = p.k0 + k;
+            uint64_t seed = p.seed;
+            if (p.group_seeds) { const int g = kp / p.Kg; seed = p.group_seeds[g]; kp -= g * p.Kg; }
+            const pm_u32x4 x = pm_philox4x32((uint32_t)kp, (uint32_t)r, PM_STREAM_BRANCH, 0u, seed);
+            const double b0 = (-pm_log(pm_unit_oc(x.x, x.y))) / p.lam_l[r];
+            const double b1 = (-pm_log(pm_unit_oc(x.z, x.w))) / p.lam_r[r];
+            p.bl[i] = b0;
+            p.br[i] = b1;
+            sb[2 * pair] = b0;
+            sb[2 * pair + 1] = b1;
+#pragma unroll
+            for (int sd = 0; sd < 2; ++sd) {
+                const double nrm = (sd ? b1 : b0) * qn;
+                const int c = (nrm > 1.495585217958292e-2) + (nrm > 2.539398330063230e-1) + (nrm > 9.504178996162932e-1) +
+                              (nrm > 2.097847961257068e0);
+                cls[u][sd] = c;
+                pos[u][sd] = atomicAdd(&scount[c], 1);
+            }
+        }
+    }
+    __syncthreads();
+    int off[5];
+    off[0] = 0;
+#pragma unroll
+    for (int c = 1; c < 5; ++c) off[c] = off[c - 1] + scount[c - 1];
+#pragma unroll
+    for (int u = 0; u < PK_DRAW_ITEMS / 512; ++u)
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd)
+            if (cls[u][sd] >= 0) {
+                const int c = cls[u][sd];
+                const int o = c == 0 ? off[0] : c == 1 ? off[1] : c == 2 ? off[2] : c == 3 ? off[3] : off[4];
+                slist[o + pos[u][sd]] = (unsigned short)(2 * (u * NT + tid) + sd);
+            }
+    __syncthreads();
+    // (a matrix is one 128-byte line of Pmat; eight lanes writing one line, 16 bytes each, through LDS: measured, no gain)
+    const int nitems = total - base < PK_DRAW_ITEMS ? total - base : PK_DRAW_ITEMS;
+    #pragma unroll 1
+    for (int sidx = tid; sidx < nitems; sidx += NT) {
+        const int li = slist[sidx], t = base + li;
+        double pm[16];
+        pm_expm4(q, sb[li], pm);
+        double* out = p.Pmat + (size_t)(t >> 1) * 32 + (t & 1) * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) out[j] = pm[j];
+    }
+}
+
+template <int NT, bool SORTED>
+__device__ __forceinline__ void pk_sweep_prologue_body(const pk_prologue_args& p) {
     const int b = blockIdx.x;
     if (b < p.draw_blocks) {
-        pk_sweep_draws_body(b * 64 + (int)threadIdx.x, p.Q, p.lam_l, p.lam_r, p.jc, p.seed, p.R, p.Kloc, p.k0, p.bl, p.br, p.Pmat, p.Kg,
-                            p.group_seeds);
+        if constexpr (SORTED) pk_sweep_draws_sorted(b, p);
+        else pk_sweep_draws_body(b * NT + (int)threadIdx.x, p.Q, p.lam_l, p.lam_r, p.jc, p.seed, p.R, p.Kloc, p.k0, p.bl, p.br, p.Pmat, p.Kg,
+                                 p.group_seeds);
     } else if (b < p.draw_blocks + p.init_blocks) {
-        const int i0 = ((b - p.draw_blocks) * 64 + (int)threadIdx.x) * 4;
+        const int i0 = ((b - p.draw_blocks) * NT + (int)threadIdx.x) * 4;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u;
@@ -209,10 +296,10 @@ __global__ __launch_bounds__(64) void pk_sweep_prologue(const pk_prologue_args p
             }
         }
     } else if (b < p.draw_blocks + p.init_blocks + p.mark_blocks) {
-        const unsigned int w = (unsigned int)((b - p.draw_blocks - p.init_blocks) * 64 + (int)threadIdx.x) * 4u;
+        const unsigned int w = (unsigned int)((b - p.draw_blocks - p.init_blocks) * NT + (int)threadIdx.x) * 4u;
         if (w < p.mark_words) *reinterpret_cast<uint4*>(p.mark + w) = make_uint4(0u, 0u, 0u, 0u);
     } else {                                              // the draw the index search of rank event r >= 1 scales by the cdf total
-        const long i = (long)(b - p.draw_blocks - p.init_blocks - p.mark_blocks) * 64 + (int)threadIdx.x + p.K;   // rows 1 .. R-1
+        const long i = (long)(b - p.draw_blocks - p.init_blocks - p.mark_blocks) * NT + (int)threadIdx.x + p.K;   // rows 1 .. R-1
         if (i < (long)p.R * p.K) {
             const int r = (int)(i / p.K);
             int kp = (int)(i - (long)r * p.K);
@@ -223,6 +310,8 @@ __global__ __launch_bounds__(64) void pk_sweep_prologue(const pk_prologue_args p
         }
     }
 }
+__global__ __launch_bounds__(64) void pk_sweep_prologue(const pk_prologue_args p) { pk_sweep_prologue_body<64, false>(p); }
+__global__ __launch_bounds__(256) void pk_sweep_prologue_sorted(const pk_prologue_args p) { pk_sweep_prologue_body<256, true>(p); }
 
 // ------------------------------------------------------------------------------------------------
 // canonical sum_s log(pi . x[s]) of `rows` vectors [S,4]; one wave per row, its tiles (T sites) one after the other.
@@ -1648,9 +1737,6 @@ __device__ __forceinline__ void pk_rows_run(int s0, int s1, const char* bl, cons
         }
     }
 }
-// LDS written by some lanes of a wave and read by others of the SAME wave: the LDS pipe serves a wave's instructions in
-// order, so only the compiler has to be kept from moving the reads up
-__device__ __forceinline__ void pk_wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // one tile of one merge by one wave; the tables are the wave's own slices of LDS
 template <bool CL, bool CR>
 __device__ __forceinline__ void pk_rows_loop(int s0, int s1, const double* Lp, const double* Rp, const uint8_t* Lc, const uint8_t* Rc,

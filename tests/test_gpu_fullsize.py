@@ -201,10 +201,11 @@ def test_whole_sweep_forms_quirk_flag_generic_rows_and_special_values():
         ctx.close()
 
 
-@pytest.mark.parametrize("G,Kg", [(3, 32), (8, 256), (5, 7), (10, 2048)])
+@pytest.mark.parametrize("G,Kg", [(3, 32), (8, 256), (5, 7), (10, 2048), (13, 1000)])
 def test_batched_sweeps_in_every_form(G, Kg):
     """G independent sweeps per set of launches (one launch: every group has its own arrival counter; launches per rank
-    event: one scan workgroup per group): each group is bit for bit the Kg-particle sweep of its seed."""
+    event: one scan workgroup per group): each group is bit for bit the Kg-particle sweep of its seed.  (The two largest
+    shapes take the prologue whose draws are sorted by Pade order, the last one with a partly filled last workgroup.)"""
     g = load_dataset('primate_data')['genome']
     N = g.shape[0]
     Q = O.get_Q(O.init_y_q())

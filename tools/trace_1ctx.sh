@@ -13,7 +13,7 @@ python3 - "$t" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-for name in ('pk_materialize_adopted_grouped', 'pk_rank_book_packed<8>', 'pk_rank_merge_nostore', 'pp_resample_scan'):
+for name in ('pk_sweep_prologue', 'pk_materialize_adopted_grouped', 'pk_rank_book_packed<8>', 'pp_resample_scan'):
     d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows if name in r['Kernel_Name'] and int(r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size', 0)) > 0]
     print(name, len(d), ' '.join('%.1f' % x for x in d[-33:]))
 PY
