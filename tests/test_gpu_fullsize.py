@@ -227,6 +227,31 @@ def test_batched_sweeps_in_every_form(G, Kg):
     ctx.close()
 
 
+def test_large_launch_forms_equal_the_small_launch_forms(monkeypatch):
+    """Launch sets of many particles take the 8-lane bookkeeping and the prologue sorted by Pade order; the switches bring back
+    the forms small launches use (16 lanes, index order).  Same bits either way."""
+    g = load_dataset('primate_data')['genome']
+    Q = O.get_Q(O.init_y_q())
+    G, Kg = 13, 1000
+    seeds = [5 + 3 * i for i in range(G)]
+    outs = []
+    for switches in ((), ("PHYLO_BOOK_LP16", "PHYLO_NO_SORTED_DRAWS")):
+        for sw in switches:
+            monkeypatch.setenv(sw, "1")                    # (read when the context is created)
+        ctx = ctx_for(g, G * Kg, Q)
+        ctx.sweep_batch_async(seeds, flags=_ffi.FLAGS_DEFAULT)
+        out = ctx.sweep_fetch()
+        outs.append((out, list(ctx.sweep_fetch_logz(G))))
+        ctx.close()
+    (a, za), (b, zb) = outs
+    for key in ('log_weights', 'log_likelihood', 'left_branches', 'right_branches'):
+        if key in a:
+            assert same_bits(a[key], b[key]), key
+    np.testing.assert_array_equal(a['ancestors'], b['ancestors'])
+    np.testing.assert_array_equal(a['merges'], b['merges'])
+    assert za == zb
+
+
 def test_one_launch_batches_of_different_G_on_one_context():
     """The one-launch sweep's arrival counters are per group and monotone: a batch with another number of groups that plans
     the same workgroups per group must not find stale counters in the groups the previous batch did not use (K = 6144: G = 3
