@@ -1,5 +1,5 @@
 """Random (N, S, K, model, flags, form) draws, GPU against the C oracle, bit for bit; wider ranges than the test suite's 60 draws
-(up to 70 taxa: the 16 / 32 / 64-lane and the wave-per-particle bookkeeping; batched groups; twisting; one-launch form; flat
+(up to 70 taxa: the 8 / 16 / 32 / 64-lane and the wave-per-particle bookkeeping; batched groups, small and large; twisting; one-launch form; flat
 weights; site tiles from 64 sites to the default, rows of one to nine tiles).  python tests/fuzz_parity.py [seconds] [seed]"""
 import os
 import sys
@@ -25,9 +25,12 @@ while time.time() - t0 < budget:
     N = int(rng.choice([2, 3, 5, 9, 12, 16, 17, 27, 32, 33, 40, 50, 64, 65, 70]))
     S = int(rng.choice([1, 7, 63, 64, 65, 255, 256, 257, 600, 1025, 2049, 4100]))
     T = int(rng.choice([0, 0, 64, 128, 448, 1024]))           # contract v5's site tile (0: the default); the oracle takes the same
-    mode = str(rng.choice(['plain', 'plain', 'batched', 'twist', 'one_launch', 'eager', 'flat']))
+    mode = str(rng.choice(['plain', 'plain', 'batched', 'batched_large', 'twist', 'one_launch', 'eager', 'flat']))
     Kg = int(rng.choice([1, 3, 16, 50, 129, 256, 700]))
     G = int(rng.choice([2, 3, 5])) if mode == 'batched' else 1
+    if mode == 'batched_large':                               # launch sets of >= 8192 particles: 8-lane bookkeeping, sorted prologue
+        N, S = int(rng.choice([5, 9, 12, 16])), int(rng.choice([7, 64, 257, 600]))
+        G, Kg = int(rng.choice([9, 13, 17])), int(rng.choice([700, 1000, 1024]))
     if mode == 'twist':
         N, Kg = min(N, 12), min(Kg, 50)
     if S > 2048:
