@@ -79,6 +79,12 @@ struct pg_args {
     int chunks_free_only;              // pg_parent_chunks sums the entries of free parents only (one launch for all rank events);
                                        // pg_nodes_rows adds the flagged parents' entries, which end a heavy node's list
     double* slowpart;                  // [flagged nodes][TS][PG_PART] (rows form; else NULL): their partial sums, TS tiles of 256 sites
+    unsigned int* row_done;            // [R K][TS] (pg_nodes_rows_all): == row_epoch when that tile of the node's adjoint row is complete
+    unsigned int row_epoch;            // this reverse pass's value of row_done (never 0)
+    unsigned int* row_timeout;         // set when a wait of pg_nodes_rows_all gave up
+    unsigned int* coeff_done;          // [R] or NULL: == row_epoch when pg_coeff of that rank event is complete (pg_nodes_rows_all beside the chain)
+    unsigned int* coeff_ticket;        // [R]: workgroups of that launch that have finished (the last one resets it)
+    unsigned long long coeff_mask;     // bit r: rank event r has a pg_coeff launch to wait for
     int TS;
     double *om, *G;                    // [R][K]
     double* C;                         // [R][K][N]: coefficient of sum_s log(pi . X) of every root slot after rank event r
@@ -238,51 +244,152 @@ __global__ __launch_bounds__(64) void pg_G(pg_args a) {
 // ---- g3: root-slot coefficients, one rank event per launch (newest first) ---------------------------------
 // C_r[k][slot] = G_r[k] + sum over adopters k' of C_{r+1}[k'][position of that slot in k''s new table]
 // grid (K -- or the adopted particles of rank event r, adp[adp0 ...] --, slot groups); 4 waves per workgroup, one slot each.
-__global__ __launch_bounds__(256) void pg_coeff(pg_args a, int r, int adp0) {
-    const int k = a.adp ? a.adp[adp0 + blockIdx.x] - r * a.K : (int)blockIdx.x, lane = threadIdx.x & 63;
-    const int slot = blockIdx.y * 4 + (threadIdx.x >> 6);
+// Values handed from one workgroup to another INSIDE a launch (pg_coeff_all, pg_nodes_rows_all) are stored and loaded at agent
+// scope (device-coherent accesses that pass the per-XCD L2), ordered by s_waitcnt + the workgroup barrier around a relaxed
+// completion word: no cache-wide write-back / invalidate per hand-off (those cost every kernel on the GPU its L2 contents -- the
+// parents' sort beside the chains ran at half speed -- and made a hand-off as slow as a launch boundary).
+__device__ __forceinline__ double pg_ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void pg_st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// bx, by: the workgroup's place in rank event r's grid (adopted particle, group of four slots); total: that grid's workgroups.
+// wait_word != NULL (pg_coeff_all): rank event r + 1's coefficients are complete when *wait_word == a.row_epoch.  Everything that
+// does not depend on them -- the adopters' indices and positions of up to PG_COEFF_PRE x 256 adopters, two dependent loads each --
+// is loaded BEFORE the wait; behind it there is one round of coefficient loads, the sum, the store and the completion word.
+#define PG_COEFF_PRE 4
+__device__ __forceinline__ void pg_coeff_body(const pg_args& a, int r, int adp0, int bx, int by, unsigned int total,
+                                              const unsigned int* wait_word) {
+    const int k = a.adp ? a.adp[adp0 + bx] - r * a.K : bx, lane = threadIdx.x & 63;
+    const int slot = by * 4 + (threadIdx.x >> 6);
     const int n1 = a.N - r - 1;
-    if (slot >= n1) return;
-    const double g = a.G[(size_t)r * a.K + k];
-    double* Ck = a.C + ((size_t)r * a.K + k) * a.N;
+    const bool active = slot < n1;                           // (per wave)
+    double g = 0.0;
     int off = 0, cnt = 0;
-    if (r + 1 < a.R) {
-        const int32_t* o = a.ad_off + (size_t)(r + 1) * (a.K + 1);
-        off = o[k];
-        cnt = o[k + 1] - off;
-    }
-    double v = 0.0;
-    if (cnt > 0) {
-        const int32_t* idx = a.ad_idx + (size_t)(r + 1) * a.K + off;
-        const size_t base = (size_t)(r + 1) * a.K;
-        // three dependent loads per adopter (index -> position -> coefficient): four adopters per lane in flight, each level's
-        // loads issued together (clamped index: no branch around a load); added in the same order as one at a time
-        for (int j0 = lane; j0 < cnt; j0 += 256) {
-            size_t row[4];
-            int p[4];
-            double cv[4], tv[4];
+    size_t row[PG_COEFF_PRE][4];
+    int p[PG_COEFF_PRE][4];
+    double tv[PG_COEFF_PRE][4];
+    const size_t base = (size_t)(r + 1) * a.K;
+    if (active) {
+        g = a.G[(size_t)r * a.K + k];
+        if (r + 1 < a.R) {
+            const int32_t* o = a.ad_off + (size_t)(r + 1) * (a.K + 1);
+            off = o[k];
+            cnt = o[k + 1] - off;
+        }
+        if (cnt > 0) {
+            // three dependent loads per adopter (index -> position -> coefficient): four adopters per lane and iteration in flight, each
+            // level's loads issued together (clamped index: no branch around a load); added in the same order as one at a time
+            const int32_t* idx = a.ad_idx + (size_t)(r + 1) * a.K + off;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + 64 * u < cnt ? j0 + 64 * u : cnt - 1;
-                row[u] = (base + idx[j]) * a.N;
-            }
+            for (int it = 0; it < PG_COEFF_PRE; ++it)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                p[u] = a.pos[row[u] + slot];
-                tv[u] = a.twist ? a.tw.ctw[row[u] + slot] : 0.0;   // the adopter's potentials subtract post() of every adopted root
-            }
+                for (int u = 0; u < 4; ++u) {
+                    const int jj = lane + 256 * it + 64 * u;
+                    row[it][u] = (base + idx[jj < cnt ? jj : cnt - 1]) * a.N;
+                }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) cv[u] = a.C[row[u] + (p[u] >= 0 ? p[u] : 0)];
+            for (int it = 0; it < PG_COEFF_PRE; ++it)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (j0 + 64 * u < cnt) {
-                    if (p[u] >= 0) v = v + cv[u];
-                    if (a.twist) v = v + tv[u];
+                for (int u = 0; u < 4; ++u) {
+                    p[it][u] = a.pos[row[it][u] + slot];
+                    tv[it][u] = a.twist ? a.tw.ctw[row[it][u] + slot] : 0.0;   // the adopter's potentials subtract post() of every adopted root
                 }
         }
-        v = pg_wave_sum(v);
     }
-    if (lane == 0) Ck[slot] = g + v;
+    if (wait_word) {                                         // (uniform)
+        if (threadIdx.x == 0) {
+            unsigned int spins = 0;
+            while (__hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.row_epoch) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 18)) {
+                    __hip_atomic_store(a.row_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (active) {
+        double v = 0.0;
+        if (cnt > 0) {
+            double cv[PG_COEFF_PRE][4];
+#pragma unroll
+            for (int it = 0; it < PG_COEFF_PRE; ++it)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double* cp = a.C + row[it][u] + (p[it][u] >= 0 ? p[it][u] : 0);
+                    cv[it][u] = a.coeff_done ? pg_ld_agent(cp) : *cp;
+                }
+#pragma unroll
+            for (int it = 0; it < PG_COEFF_PRE; ++it)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (lane + 256 * it + 64 * u < cnt) {
+                        if (p[it][u] >= 0) v = v + cv[it][u];
+                        if (a.twist) v = v + tv[it][u];
+                    }
+            const int32_t* idx = a.ad_idx + (size_t)(r + 1) * a.K + off;
+            for (int j0 = lane + 256 * PG_COEFF_PRE; j0 < cnt; j0 += 256) {      // (more than 1024 adopters of one particle)
+                size_t rw[4];
+                int pp[4];
+                double cw[4], tw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 64 * u < cnt ? j0 + 64 * u : cnt - 1;
+                    rw[u] = (base + idx[j]) * a.N;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pp[u] = a.pos[rw[u] + slot];
+                    tw[u] = a.twist ? a.tw.ctw[rw[u] + slot] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double* cp = a.C + rw[u] + (pp[u] >= 0 ? pp[u] : 0);
+                    cw[u] = a.coeff_done ? pg_ld_agent(cp) : *cp;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + 64 * u < cnt) {
+                        if (pp[u] >= 0) v = v + cw[u];
+                        if (a.twist) v = v + tw[u];
+                    }
+            }
+            v = pg_wave_sum(v);
+        }
+        if (lane == 0) {
+            double* Ck = a.C + ((size_t)r * a.K + k) * a.N;
+            if (a.coeff_done) pg_st_agent(Ck + slot, g + v); else Ck[slot] = g + v;
+        }
+    }
+    if (a.coeff_done) {                                      // (uniform) somebody waits for this launch inside another one: the last
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // workgroup to finish says that rank event r's coefficients are complete
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int t = __hip_atomic_fetch_add(a.coeff_ticket + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == total - 1) {
+                __hip_atomic_store(a.coeff_ticket + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.coeff_done + r, a.row_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void pg_coeff(pg_args a, int r, int adp0) {
+    pg_coeff_body(a, r, adp0, (int)blockIdx.x, (int)blockIdx.y, gridDim.x * gridDim.y, nullptr);
+}
+// The whole coefficient chain as ONE launch: the grids of all rank events one after the other, newest rank event first (a workgroup
+// is dispatched after everything it waits for); a workgroup of rank event r waits for the completion word of rank event r + 1
+// (coeff_done, set by the last workgroup of that rank event to finish), bounded like the waits of pg_nodes_rows_all.  Ten dependent
+// launches of 11 us + 6 us between them become one launch with a short hand-off per rank event.
+struct pg_coeff_plan { int first[66]; int adp0[66]; int ny[66]; };   // by rank event: first workgroup (descending r), adp offset, slot groups
+__global__ __launch_bounds__(256) void pg_coeff_all(pg_args a, pg_coeff_plan pl) {
+    const int b = (int)blockIdx.x;
+    int r = a.R - 2;
+    while (r > 0 && b >= pl.first[r - 1]) --r;               // first[] grows as r falls: first[R - 2] = 0
+    const int local = b - pl.first[r], ny = pl.ny[r];
+    const int bx = local / ny, by = local - bx * ny;
+    const int total = r > 0 ? pl.first[r - 1] - pl.first[r] : (int)gridDim.x - pl.first[r];
+    const bool waits = r + 1 < a.R - 1 && ((a.coeff_mask >> (r + 1)) & 1ull);   // rank event r + 1 has coefficients of its own
+    pg_coeff_body(a, r, pl.adp0[r], bx, by, (unsigned int)total, waits ? a.coeff_done + r + 1 : nullptr);
 }
 
 // ---- g4: per-leaf sums for d/d pi of the leaf terms -----------------------------------------------------
@@ -608,6 +715,93 @@ __global__ __launch_bounds__(256) void pg_nodes(pg_args a, int r) {
     }
 }
 
+// pg_parent_chunks in ROW form: grid (groups of 64 sites, chunks), lane = site (all four states: whole 32-byte rows per load, no
+// quad broadcasts -- the quad form above spends 24 of its ~50 instructions per quarter site on DPP moves), wave w gathers
+// parents w PG_PCHUNK .. of the chunk for the same 64 sites, the four partial sums are added in wave order.  Every sibling row
+// of a wave's parents is loaded before the first is used.  Same sum per chunk up to the order inside a 4-term dot product.
+__global__ __launch_bounds__(256) void pg_parent_chunks_rows(pg_args a, int chunk0) {
+    static_assert(PG_HCHUNK == 4 * PG_PCHUNK, "one wave per PG_PCHUNK parents of a chunk");
+    __shared__ double shP[PG_HCHUNK][32];
+    __shared__ int shE[PG_HCHUNK];
+    __shared__ int shSib[PG_HCHUNK];
+    __shared__ double shA[PG_HCHUNK];
+    __shared__ int shMe;
+    __shared__ double shX[4][4][64];
+    const int ci = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = a.chunk_beg[chunk0 + ci], cnt = a.chunk_cnt[chunk0 + ci];
+    const size_t row = (size_t)a.S * 4;
+    const int s = blockIdx.x * 64 + lane;
+    const bool live = s < a.S;
+    const size_t so = (size_t)(live ? s : a.S - 1) * 4;
+    for (int i = tid; i < cnt * 32; i += 256) {
+        const int e = i >> 5, q = i & 31;
+        const int enc = a.par_idx[c0 + e];
+        const int pn = (enc & (PG_FREE_PARENT - 1)) >> 1, side = enc & 1;
+        shP[e][q] = a.Pmat[(size_t)pn * 32 + q];
+        if (q == 0) { shE[e] = enc; shSib[e] = a.child[(size_t)pn * 2 + (1 - side)]; }
+        if (q == 1) shA[e] = pg_alpha_of(a, pn);
+        if (i == 2) shMe = a.child[(size_t)pn * 2 + side];   // the node all these are parents of
+    }
+    __syncthreads();
+    const int nc = cnt - wv * PG_PCHUNK < PG_PCHUNK ? cnt - wv * PG_PCHUNK : PG_PCHUNK;
+    double xb[4] = {0.0, 0.0, 0.0, 0.0};
+    if (nc > 0) {
+        const int e0 = wv * PG_PCHUNK;
+        const double* merow = pg_row(a, shMe) + so;
+        double x[4], sb[PG_PCHUNK][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = merow[j];
+#pragma unroll
+        for (int e = 0; e < PG_PCHUNK; ++e) {
+            const double* sr = pg_row(a, shSib[e0 + (e < nc ? e : nc - 1)]) + so;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sb[e][j] = sr[j];
+        }
+        const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
+#pragma unroll
+        for (int e = 0; e < PG_PCHUNK; ++e) {
+            if (e < nc) {                                    // wave-uniform
+                const int enc = __builtin_amdgcn_readfirstlane(shE[e0 + e]);
+                if (a.chunks_free_only && !(enc & PG_FREE_PARENT)) continue;   // a flagged parent: pg_nodes_rows adds it
+                const int side = enc & 1;
+                const double* Psib = shP[e0 + e] + (1 - side) * 16;
+                const double* Pme = shP[e0 + e] + side * 16;
+                double w[4], xp[4], t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    w[j] = pg_dot4(sb[e][0], Psib[j], sb[e][1], Psib[4 + j], sb[e][2], Psib[8 + j], sb[e][3], Psib[12 + j]);
+                if (enc & PG_FREE_PARENT) {                  // alpha_p pi / (pi . X_p),  X_p = (me P_me) o (sib P_sib)
+                    double lik = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        lik = __builtin_fma(pi[j] * w[j], pg_dot4(x[0], Pme[j], x[1], Pme[4 + j], x[2], Pme[8 + j], x[3], Pme[12 + j]), lik);
+                    const double ai = shA[e0 + e] * pg_rcp(lik);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xp[j] = pi[j] * ai;
+                } else {                                     // a parent with parents of its own (rare in a heavy node's list): its stored row
+                    const double* xpp = a.adj + (size_t)(enc >> 1) * row + so;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xp[j] = xpp[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = xp[j] * w[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xb[j] = xb[j] + pg_dot4(t[0], Pme[j * 4], t[1], Pme[j * 4 + 1], t[2], Pme[j * 4 + 2], t[3], Pme[j * 4 + 3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) shX[wv][j][lane] = xb[j];
+    __syncthreads();
+    if (wv == 0 && live) {
+        double* out = a.cpart + (size_t)ci * row + so;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = ((shX[0][j][lane] + shX[1][j][lane]) + shX[2][j][lane]) + shX[3][j][lane];
+    }
+}
+
 // The 36 sums of a node over the 256 threads of its workgroup (fixed order): per wave through its own LDS rows, then the four
 // waves in order; thread t < PG_PART writes sum t.
 struct pg_rows_lds {
@@ -754,15 +948,25 @@ __global__ __launch_bounds__(256, 3) void pg_nodes_free(pg_args a, int phase) {
 // of latencies, not throughput: every load of a thread is issued as early as possible, nothing goes through memory between the
 // adjoint row and the matrix adjoints, and the register count (occupancy 2) does not matter.  The 36 sums of a (node, tile) go
 // to slowpart; pg_node_finish adds the tiles in order.
-__global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int slow0, int chunk0) {
+// ALL = false: the flagged nodes of rank event r (a launch per rank event, newest first: a node's flagged parents are complete when
+//   its launch starts).
+// ALL = true: every flagged node of the sweep in ONE launch, newest rank event first in the grid (workgroups are dispatched in
+//   grid order, so what a workgroup waits for was dispatched before it).  A workgroup does everything that does not need its
+//   flagged parents -- its rows, matrices, the own term, the chunk sums of the free parents, the staging -- and only then waits
+//   for the (parent, same tile) workgroups it gathers from: row_done[parent TS + tile] == epoch, set by the parent's workgroup
+//   behind an agent-scope release of its adjoint tile.  The wait is bounded (row_timeout).  The chain of ten launches at their
+//   latency floors becomes one launch whose dependent part is the flagged parents' gather alone.
+template <bool ALL>
+__device__ __forceinline__ void pg_nodes_rows_body(const pg_args& a, int r_arg, int slow0, int chunk0) {
     __shared__ double shP[PG_PCHUNK][32];
     __shared__ int shE[PG_PCHUNK];
     __shared__ int shSib[PG_PCHUNK];
     __shared__ double shA[PG_PCHUNK];
     __shared__ pg_rows_lds sh;
     const int tid = threadIdx.x;
-    const int si = slow0 + blockIdx.x;
+    const int si = ALL ? slow0 - 1 - (int)blockIdx.x : slow0 + (int)blockIdx.x;     // (ALL: slow0 = the number of flagged nodes)
     const size_t node = (size_t)a.slow_idx[si];
+    const int r = ALL ? (int)(node / (size_t)a.K) : r_arg;
     const bool has_x = (a.slow_flag[node] & 2) != 0;        // pg_twist_xsum left the look-ahead merges' share in the adjoint row
     const size_t row = (size_t)a.S * 4;
     const int s = blockIdx.y * 256 + tid;
@@ -775,7 +979,6 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
     double x[4], L[4], Rv[4], xb[4], x0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { x[i] = xrow[so + i]; L[i] = Lrow[so + i]; Rv[i] = Rrow[so + i]; x0[i] = has_x ? orow[so + i] : 0.0; }
-    const double alpha = a.C[node * a.N + (a.N - r - 2)];
     const double pi[4] = {a.pi[0], a.pi[1], a.pi[2], a.pi[3]};
     const int pbeg = a.par_off[node], pend = a.par_off[node + 1];
     const int hv = a.heavy_first[node];
@@ -807,6 +1010,23 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
 #pragma unroll
     for (int i = 0; i < PG_PART; ++i) acc[i] = 0.0;
     const double lik = pg_dot4(pi[0], x[0], pi[1], x[1], pi[2], x[2], pi[3], x[3]);
+    if constexpr (ALL) {                                     // the launch runs beside the coefficient chain: rank event r's must be complete
+        if (a.coeff_done && ((a.coeff_mask >> r) & 1ull)) {  // (uniform)
+            if (tid == 0) {
+                unsigned int spins = 0;
+                while (__hip_atomic_load(a.coeff_done + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.row_epoch) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 18)) {
+                        __hip_atomic_store(a.row_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+        }
+    }
+    const double alpha = ALL ? pg_ld_agent(a.C + node * a.N + (a.N - r - 2)) : a.C[node * a.N + (a.N - r - 2)];
     const double inv = alpha * pg_rcp(lik);
 #pragma unroll
     for (int j = 0; j < 4; ++j) xb[j] = pi[j] * inv + x0[j];
@@ -835,6 +1055,24 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
             pg_stage_parents(a, tail_beg + st, nc, shP, shE, shSib, shA);
             __syncthreads();
         }
+        if constexpr (ALL) {                                 // the flagged parents of this batch: their tiles must be complete
+            if (tid < nc) {
+                const int enc = shE[tid];
+                if (!(enc & PG_FREE_PARENT)) {
+                    const unsigned int* f = a.row_done + (size_t)(enc >> 1) * a.TS + blockIdx.y;
+                    unsigned int spins = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.row_epoch) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 18)) {                 // (~0.3 s; a wait lasts microseconds)
+                            __hip_atomic_store(a.row_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         for (int e0 = 0; e0 < nc; e0 += 4) {                 // four at a time, loads first
             double xp[4][4], sb[4][4];
 #pragma unroll
@@ -847,7 +1085,7 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
                 if (!(enc & PG_FREE_PARENT)) {
                     const double* xpp = a.adj + (size_t)(enc >> 1) * row + so;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) xp[u][j] = xpp[j];
+                    for (int j = 0; j < 4; ++j) xp[u][j] = ALL ? pg_ld_agent(xpp + j) : xpp[j];
                 }
             }
 #pragma unroll
@@ -882,7 +1120,7 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
     if (live) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            orow[so + j] = xb[j];
+            if constexpr (ALL) pg_st_agent(orow + so + j, xb[j]); else orow[so + j] = xb[j];
             acc[32 + j] = x[j] * inv;
         }
 #pragma unroll
@@ -897,8 +1135,15 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
             }
         }
     }
+    if constexpr (ALL) {                                     // this tile of the adjoint row is complete: release it, then say so
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave's agent-scope stores are acknowledged
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.row_done + node * a.TS + blockIdx.y, a.row_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     pg_rows_reduce(acc, sh, a.slowpart + ((size_t)si * gridDim.y + blockIdx.y) * PG_PART);
 }
+__global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int slow0, int chunk0) { pg_nodes_rows_body<false>(a, r, slow0, chunk0); }
+__global__ __launch_bounds__(256, 2) void pg_nodes_rows_all(pg_args a, int n_slow) { pg_nodes_rows_body<true>(a, 0, n_slow, 0); }
 
 // ---- g6: per node: tiles -> Pl_bar, Pr_bar -> branch adjoints and the Q adjoint ----------------------------
 __global__ __launch_bounds__(64) void pg_node_finish(pg_args a) {

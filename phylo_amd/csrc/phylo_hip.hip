@@ -51,7 +51,7 @@ struct env_switches {
     bool eager_nodes = false, rehearse_sharded = false, replicated_book = false, fuse_scan = false,
          book_one_per_wave = false, merge_pair_form = false, no_leaf_codes = false, one_launch = false,
          persist_stamps = false, separate_materialise = false, grad_one_stream = false, grad_two_streams = false, rev_host_lists = false, no_remote_cache = false, no_spin_wait = false,
-         no_p2p = false, book_lp16 = false, no_sorted_draws = false;
+         no_p2p = false, book_lp16 = false, no_sorted_draws = false, grad_quad_chunks = false, grad_rows_chain = false, grad_rows_no_overlap = false, grad_coeff_chain = false, grad_sort_late = false;
     int persist_wgs = 0;                 // PHYLO_PERSIST_WGS: resident workgroups of the one-launch sweep (0 = default)
     unsigned long long p2p_wait_ticks = PK_P2P_WAIT_TICKS;   // PHYLO_P2P_WAIT_S: bound of a flag wait of the device-side exchange
     size_t p2p_copy_words = 65536;       // PHYLO_P2P_COPY_WORDS: exchanges beyond this many doubles copy with many workgroups (tests lower it)
@@ -66,6 +66,11 @@ struct env_switches {
         book_one_per_wave = getenv("PHYLO_BOOK_ONE_PER_WAVE") != nullptr;
         book_lp16 = getenv("PHYLO_BOOK_LP16") != nullptr;
         no_sorted_draws = getenv("PHYLO_NO_SORTED_DRAWS") != nullptr;
+        grad_quad_chunks = getenv("PHYLO_GRAD_QUAD_CHUNKS") != nullptr;
+        grad_rows_chain = getenv("PHYLO_GRAD_ROWS_CHAIN") != nullptr;
+        grad_rows_no_overlap = getenv("PHYLO_GRAD_ROWS_NO_OVERLAP") != nullptr;
+        grad_coeff_chain = getenv("PHYLO_GRAD_COEFF_CHAIN") != nullptr;
+        grad_sort_late = getenv("PHYLO_GRAD_SORT_LATE") != nullptr;
         merge_pair_form = getenv("PHYLO_MERGE_PAIR_FORM") != nullptr;
         no_leaf_codes = getenv("PHYLO_NO_LEAF_CODES") != nullptr;
         one_launch = getenv("PHYLO_ONE_LAUNCH") != nullptr;
@@ -191,6 +196,8 @@ struct phylo_ctx {
     hipEvent_t ev_leaves = nullptr;
     uint32_t *h_pub = nullptr, *hd_pub = nullptr;
     int32_t *h_dlmeta = nullptr, *hd_dlmeta = nullptr;   // what pg_dl_lists tells the host (phylo_revlists_dev.h), pinned
+    unsigned int* d_row_done = nullptr;  // [R K][tiles of 256 sites]: pg_nodes_rows_all's "this tile of the adjoint row is complete" words
+    unsigned int row_epoch = 0;          // their value in the current reverse pass
     hipEvent_t ev_dl = nullptr;
     size_t dl_temp_p = 0, dl_temp_nn = 0;   // rocPRIM's temporary storage for the parents' sort at this R K
     hipGraphExec_t dl_graph = nullptr;     // that sort's launches, captured (dev_lists_launch)
@@ -334,6 +341,8 @@ void free_sweep_state(phylo_ctx* c) {
     if (c->h_child_p) (void)hipHostFree(c->h_child_p);
     if (c->h_rad_p) (void)hipHostFree(c->h_rad_p);
     if (c->h_pub) (void)hipHostFree(c->h_pub);
+    if (c->d_row_done) (void)hipFree(c->d_row_done);
+    c->d_row_done = nullptr;
     if (c->h_dlmeta) (void)hipHostFree(c->h_dlmeta);
     c->h_dlmeta = c->hd_dlmeta = nullptr;
     if (c->ev_dl) (void)hipEventDestroy(c->ev_dl);
@@ -505,7 +514,8 @@ int ensure_graph_state(phylo_ctx* c) {
         HIPCHK(c, hipHostMalloc((void**)&c->h_pub, 16));   // log Z-hat (8 bytes) and the timeout word of a sweep that keeps its graph
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_pub, c->h_pub, 0));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_gcopy, hipEventDisableTiming));
-        HIPCHK(c, hipHostMalloc((void**)&c->h_dlmeta, (size_t)PG_DL_META_INTS(R) * 4));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_dlmeta, ((size_t)PG_DL_META_INTS(R) + 4) * 4));   // (+ the timeout word of pg_nodes_rows_all)
+        c->h_dlmeta[PG_DL_META_INTS(R)] = 0;
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->hd_dlmeta, c->h_dlmeta, 0));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_dl, hipEventDisableTiming));
         c->dl_temp_nn = 0;
@@ -1834,9 +1844,10 @@ static int dev_lists_adopters(phylo_ctx* c, const pg_dl_args& d, hipStream_t s) 
     return launch_check(c, "pg_dl_adopters");
 }
 }  // extern "C++"
-// Everything on sL; ev_dl is recorded when the lists that the coefficient chain and the host need are there (pg_dl_lists), the
-// parents' sort follows.  Nothing here waits for the host; dev_lists_wait does.
-static int dev_lists_launch(phylo_ctx* c, hipStream_t sL) {
+// The list kernels on sL; ev_dl is recorded when the lists that the coefficient chain and the host need are there (pg_dl_lists);
+// the parents' sort on sS (sort = false: the caller issues it later with dev_lists_sort).  Nothing here waits for the host;
+// dev_lists_wait does.
+static int dev_lists_launch(phylo_ctx* c, hipStream_t sL, hipStream_t sS, bool kernels = true, bool sort = true) {
     const int N = c->N, K = c->K, R = N - 1;
     const size_t nn = (size_t)R * K, nb = (nn + PG_DL_BLOCK - 1) / PG_DL_BLOCK;
     const size_t meta_ints = (size_t)PG_DL_META_INTS(R);
@@ -1862,19 +1873,23 @@ static int dev_lists_launch(phylo_ctx* c, hipStream_t sL) {
     }
     void* tp = nullptr;
     CHK(scratch_get(c, 9, c->dl_temp_p + 16, &tp));
-    if (K <= 1024) CHK(dev_lists_adopters<1>(c, d, sL));
-    else if (K <= 2048) CHK(dev_lists_adopters<2>(c, d, sL));
-    else if (K <= 4096) CHK(dev_lists_adopters<4>(c, d, sL));
-    else CHK(dev_lists_adopters<8>(c, d, sL));
-    if (R > 1) {
-        hipLaunchKernelGGL(pg_dl_count, dim3(cdiv((long)(2 * nn - 2 * (size_t)K), 256)), dim3(256), 0, sL, d);
-        CHK(launch_check(c, "pg_dl_count"));
+    if (kernels) {
+        if (K <= 1024) CHK(dev_lists_adopters<1>(c, d, sL));
+        else if (K <= 2048) CHK(dev_lists_adopters<2>(c, d, sL));
+        else if (K <= 4096) CHK(dev_lists_adopters<4>(c, d, sL));
+        else CHK(dev_lists_adopters<8>(c, d, sL));
+        if (R > 1) {
+            hipLaunchKernelGGL(pg_dl_count, dim3(cdiv((long)(2 * nn - 2 * (size_t)K), 256)), dim3(256), 0, sL, d);
+            CHK(launch_check(c, "pg_dl_count"));
+        }
+        hipLaunchKernelGGL(pg_dl_sums, dim3((unsigned)nb), dim3(PG_DL_BLOCK), 0, sL, d);
+        CHK(launch_check(c, "pg_dl_sums"));
+        hipLaunchKernelGGL(pg_dl_lists, dim3((unsigned)nb), dim3(PG_DL_BLOCK), 0, sL, d);
+        CHK(launch_check(c, "pg_dl_lists"));
+        HIPCHK(c, hipEventRecord(c->ev_dl, sL));
     }
-    hipLaunchKernelGGL(pg_dl_sums, dim3((unsigned)nb), dim3(PG_DL_BLOCK), 0, sL, d);
-    CHK(launch_check(c, "pg_dl_sums"));
-    hipLaunchKernelGGL(pg_dl_lists, dim3((unsigned)nb), dim3(PG_DL_BLOCK), 0, sL, d);
-    CHK(launch_check(c, "pg_dl_lists"));
-    HIPCHK(c, hipEventRecord(c->ev_dl, sL));
+    if (!sort) return PHYLO_OK;
+    sL = sS;
     // the parents' sort: six small launches through rocPRIM's host code, 8 us of host time each -- captured once per shape (the
     // buffers are the context's own and stay where they are), replayed with one call
     const void* key[4] = {ws, tp, (const void*)c->d_ad_off, (const void*)nn};
@@ -1968,13 +1983,22 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
     }
     HIPCHK(c, hipEventRecord(c->evb0, c->stream));
     const int nrk = cdiv((long)R * K, 256);
+    // a lazy sweep left marks: a node nobody adopted has no parents and alpha = omega, known without any list -- nearly all
+    // nodes, done while the lists are built
+    const bool early_free = rows_form && !twist && c->last_graph_marks;
+    // After a lazy sweep with the plain proposal the lists are built by kernels (phylo_revlists_dev.h) and the host waits for a few
+    // dozen integers; PHYLO_REV_HOST_LISTS keeps the host builders (the A/B switch, and what every other form uses).
+    const bool dev_lists = early_free && !c->env.rev_host_lists && c->Kloc == K && K <= PG_DL_MAX_K;
+    // The list kernels need the sweep's ancestors and children and nothing else: they are queued right behind the sweep on its own
+    // stream, ahead of the early kernels below (they head the longest chain: lists -> sort -> chunk sums -> adopted nodes).
+    // (their sort goes to the second stream as soon as the host has seen the sweep end: queued there behind the lists' event, it
+    //  neither waits for the host to read the counts nor holds up the coefficient chain on this stream)
+    const bool sort_early = dev_lists && !c->env.grad_sort_late && !c->env.grad_one_stream;
+    if (dev_lists) CHK(dev_lists_launch(c, c->stream, c->stream, true, false));
     hipLaunchKernelGGL(pg_omega, dim3(nrk), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_omega"));
     hipLaunchKernelGGL(pg_leafpi, dim3(N), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_leafpi"));
-    // a lazy sweep left marks: a node nobody adopted has no parents and alpha = omega, known without any list -- nearly all
-    // nodes, done while the host builds the lists
-    const bool early_free = rows_form && !twist && c->last_graph_marks;
     g.alpha_om = early_free ? 1 : 0;                       // a free parent then is a node nobody adopted: alpha = omega
     // That launch is 85 us of throughput work nothing waits for before pg_node_finish, while everything else below is a chain of
     // small dependent launches: it runs on a stream of the lowest priority, in the background of the chains.
@@ -2034,9 +2058,6 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         HIPCHK(c, hipEventRecord(c->ev_bgdone, c->bgstream));
         return PHYLO_OK;
     };
-    // After a lazy sweep with the plain proposal the lists are built by kernels (phylo_revlists_dev.h) and the host waits for a few
-    // dozen integers; PHYLO_REV_HOST_LISTS keeps the host builders (the A/B switch, and what every other form uses).
-    const bool dev_lists = early_free && !c->env.rev_host_lists && c->Kloc == K && K <= PG_DL_MAX_K;
     dl_meta dm;
     if (bg_free && !dev_lists) CHK(launch_bg_free());
     const auto host_t0 = std::chrono::steady_clock::now();
@@ -2066,8 +2087,11 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
     // (the host has seen the sweep end: the second stream needs no event to start on its outputs, and the list kernels run
     //  beside the early kernels)
     if (dev_lists) {
-        CHK(dev_lists_launch(c, sB));
-        if (two) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_dl, 0));   // the coefficient chain reads the adopters' lists
+        // (the list kernels run on the context's stream, ahead of the coefficient chain)
+        if (sort_early) {
+            HIPCHK(c, hipStreamWaitEvent(c->gstream, c->ev_dl, 0));
+            CHK(dev_lists_launch(c, c->gstream, c->gstream, false, true));
+        }
         // the list kernels are workgroups of 1024 threads that everything else waits for: on a GPU that the background launch has
         // filled they wait for a whole free CU each, kernel after kernel (lists ready after 120 us instead of 55): the background
         // launch starts behind them.  (Measured, primate.p K = 2048 / DS1 K = 4096, reverse pass: background launch first 0.504 /
@@ -2086,6 +2110,25 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
     pg_parents_info pinfo{};
     size_t max_chunks = 0, n_chunks = 0;
     if (early_free && !dev_lists) pg_mark_adopted(R, K, anc, L);
+    // the adopted nodes' chain as ONE launch (pg_nodes_rows_all; the plain proposal with the lists built on the device): the
+    // coefficient chain -- then the longest chain of the pass -- is issued first and in one go, the parents' sort and the chunk sums
+    // behind it, and the one launch waits for the last coefficients
+    bool rows_all = false, rows_overlap = false;
+    auto launch_chunks = [&]() -> int {
+        // The parents of a heavy node are nearly all nodes nobody merged again: their share of the node's adjoint needs their
+        // alpha = omega and nothing else.  ONE launch sums
+        // them for the chunks of all rank events; the chain below is then pg_nodes_rows alone, which adds the flagged parents.
+        const size_t rowlen = (size_t)S * 4;
+        for (size_t cbeg = 0; cbeg < n_chunks; cbeg += 65535) {
+            const size_t cn = n_chunks - cbeg < 65535 ? n_chunks - cbeg : 65535;
+            pg_args g2 = g;
+            g2.cpart = g.cpart + cbeg * rowlen;
+            if (c->env.grad_quad_chunks) hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), (unsigned)cn), dim3(256), 0, sB, g2, (int)cbeg);
+            else hipLaunchKernelGGL(pg_parent_chunks_rows, dim3(cdiv(S, 64), (unsigned)cn), dim3(256), 0, sB, g2, (int)cbeg);
+            CHK(launch_check(c, "pg_parent_chunks"));
+        }
+        return PHYLO_OK;
+    };
     auto parents_block = [&]() -> int {
     // ---- parents, heavy nodes' chunks, flagged nodes by rank event (pg_build_parents, or what pg_dl_lists reports)
     if (dev_lists) {
@@ -2127,19 +2170,34 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         CHK(launch_check(c, "pg_copy_words"));
         if (two) HIPCHK(c, hipEventRecord(c->ev_gup, sB));
     }
-    if (early_free && n_chunks > 0) {
-        // The parents of a heavy node are nearly all nodes nobody merged again: their share of the node's adjoint needs their
-        // alpha = omega and nothing else.  ONE launch sums
-        // them for the chunks of all rank events; the chain below is then pg_nodes_rows alone, which adds the flagged parents.
-        const size_t rowlen = (size_t)S * 4;
-        for (size_t cbeg = 0; cbeg < n_chunks; cbeg += 65535) {
-            const size_t cn = n_chunks - cbeg < 65535 ? n_chunks - cbeg : 65535;
-            pg_args g2 = g;
-            g2.cpart = g.cpart + cbeg * rowlen;
-            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), (unsigned)cn), dim3(256), 0, sB, g2, (int)cbeg);
-            CHK(launch_check(c, "pg_parent_chunks"));
+    rows_all = rows_form && early_free && dev_lists && two && !c->env.grad_rows_chain && pinfo.n_slow > 0 &&
+               (size_t)pinfo.n_slow * (size_t)g.TS <= 16384;
+    if (rows_all) {
+        if (!c->d_row_done) {
+            const size_t words = (size_t)R * K * (size_t)cdiv(c->S, 256) + 2 * (size_t)R;   // + coeff_done[R] | coeff_ticket[R]
+            CHK(dalloc(c, &c->d_row_done, words));
+            HIPCHK(c, hipMemsetAsync(c->d_row_done, 0, words * 4, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));     // (once per context: ahead of every launch, on any stream, that touches them)
+            c->row_epoch = 0;
         }
+        if (++c->row_epoch == 0) ++c->row_epoch;             // (0 is what the words hold before their first pass)
+        g.row_done = c->d_row_done;
+        g.row_epoch = c->row_epoch;
+        g.row_timeout = (unsigned int*)(c->hd_dlmeta + PG_DL_META_INTS(R));
+        // few enough workgroups to leave the coefficient chain room on every SIMD: the launch runs BESIDE that chain and waits, rank
+        // event by rank event, for its completion words; else it is launched behind the chain's last event
+        rows_overlap = (size_t)pinfo.n_slow * (size_t)g.TS <= 512 && !c->env.grad_rows_no_overlap;
+        g.coeff_done = c->d_row_done + (size_t)R * K * (size_t)cdiv(c->S, 256);
+        g.coeff_ticket = g.coeff_done + R;
+        g.coeff_mask = 0ull;
+        for (int r = 0; r + 1 < R; ++r)
+            if (dm.ev_adp0[r + 1] > dm.ev_adp0[r]) g.coeff_mask |= 1ull << r;
     }
+    // (the launch behind the coefficient chain: that chain is the longer one and is issued first; the launch beside it: the sort and
+    //  the chunk sums first, so that the adopted nodes follow the coefficients rank event by rank event)
+    const bool q3_first = !rows_all || rows_overlap;
+    if (dev_lists && q3_first && !sort_early) CHK(dev_lists_launch(c, sB, sB, false, true));   // the parents' sort (the host has seen the list kernels end)
+    if (early_free && n_chunks > 0 && q3_first) CHK(launch_chunks());
         return PHYLO_OK;
     };
     if (reorder || dev_lists) CHK(parents_block());
@@ -2152,7 +2210,7 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
     const size_t ad_ints = (size_t)R * (K + 1) + nn;
     // With the parents' lists already there, the two chains are launched in turn, a rank event of each: the host needs ~3 us per
     // call, and the adopted nodes' chain queued behind all the coefficient launches would start ~70 us late.
-    const bool interleave = early_free && two && (reorder || dev_lists);
+    const bool interleave = early_free && two && (reorder || dev_lists) && !rows_all;
     auto launch_coeff = [&](int r) -> int {
         const int na = ev_adp0[r + 1] - ev_adp0[r];
         if (na > 0) {
@@ -2171,8 +2229,23 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
             CHK(launch_check(c, "pg_G"));
         }
         if (two) HIPCHK(c, hipEventRecord(c->ev_coeff[R - 1], c->stream));   // (the last rank event has no adopters: C is there)
-        if (!interleave)
+        // with the adopted nodes in one launch, the coefficient chain is one launch too (pg_coeff_all) when all of its workgroups
+        // can be resident
+        long coeff_wgs = 0;
+        for (int r = R - 2; r >= 0; --r) coeff_wgs += (long)(ev_adp0[r + 1] - ev_adp0[r]) * cdiv(N - r - 1, 4);
+        if (rows_all && R - 1 <= 64 && coeff_wgs > 0 && coeff_wgs <= 2048 && !c->env.grad_coeff_chain) {
+            pg_coeff_plan pl{};
+            int at = 0;
+            for (int r = R - 2; r >= 0; --r) {
+                pl.first[r] = at; pl.adp0[r] = ev_adp0[r]; pl.ny[r] = cdiv(N - r - 1, 4);
+                at += (ev_adp0[r + 1] - ev_adp0[r]) * pl.ny[r];
+            }
+            hipLaunchKernelGGL(pg_coeff_all, dim3((unsigned)at), dim3(256), 0, c->stream, g, pl);
+            CHK(launch_check(c, "pg_coeff_all"));
+            if (two) HIPCHK(c, hipEventRecord(c->ev_coeff[0], c->stream));
+        } else if (!interleave) {
             for (int r = R - 2; r >= 0; --r) CHK(launch_coeff(r));
+        }
     } else {
         hipLaunchKernelGGL(pg_G, dim3(R * K), dim3(64), 0, c->stream, g);
         CHK(launch_check(c, "pg_G"));
@@ -2290,7 +2363,17 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         hipLaunchKernelGGL(pg_nodes_free, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, c->stream, g, 1);
         CHK(launch_check(c, "pg_nodes_free"));
     }
-    for (int r = R - 1; r >= 0; --r) {
+    if (rows_all && !rows_overlap) {                       // (behind the coefficient launches: they head the longer chain)
+        if (!sort_early) CHK(dev_lists_launch(c, sB, sB, false, true));
+        if (n_chunks > 0) CHK(launch_chunks());
+    }
+    if (rows_all) {
+        if (!rows_overlap) HIPCHK(c, hipStreamWaitEvent(sB, c->ev_coeff[0], 0));   // every alpha is there
+        hipLaunchKernelGGL(pg_nodes_rows_all, dim3((unsigned)pinfo.n_slow, g.TS), dim3(256), 0, sB, g, (int)pinfo.n_slow);
+        CHK(launch_check(c, "pg_nodes_rows_all"));
+        ++node_launches;
+    }
+    for (int r = rows_all ? -1 : R - 1; r >= 0; --r) {
         if (interleave && r >= 1) CHK(launch_coeff(r - 1));
         if (two) HIPCHK(c, hipStreamWaitEvent(sB, c->ev_coeff[r], 0));
         if (twist && ev_chunk0[r + 1] > ev_chunk0[r]) {
@@ -2302,7 +2385,8 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         }
         const int nch = early_free ? 0 : rank_chunk0[r + 1] - rank_chunk0[r];   // (after the early pg_nodes_free: summed above, all rank events at once)
         if (nch > 0) {
-            hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), nch), dim3(256), 0, sB, g, (int)rank_chunk0[r]);
+            if (c->env.grad_quad_chunks) hipLaunchKernelGGL(pg_parent_chunks, dim3(cdiv(S, 16 * PG_CSTEPS), nch), dim3(256), 0, sB, g, (int)rank_chunk0[r]);
+            else hipLaunchKernelGGL(pg_parent_chunks_rows, dim3(cdiv(S, 64), nch), dim3(256), 0, sB, g, (int)rank_chunk0[r]);
             CHK(launch_check(c, "pg_parent_chunks"));
             ++node_launches;
         }
@@ -2340,6 +2424,11 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
     HIPCHK(c, hipEventRecord(c->ev_gjoin, c->stream));     // (free again: the stream has waited for it above)
     CHK(wait_event_spin(c, c->ev_gjoin));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (rows_all && c->h_dlmeta[PG_DL_META_INTS(R)] != 0) {
+        c->h_dlmeta[PG_DL_META_INTS(R)] = 0;
+        return fail(c, PHYLO_EHIP, "reverse pass: a workgroup of pg_nodes_rows_all gave up waiting for a parent's adjoint tile "
+                                       "(PHYLO_GRAD_ROWS_CHAIN=1 runs a launch per rank event instead)");
+    }
     if (d_lam_l) memcpy(d_lam_l, out.data(), (size_t)R * 8);
     if (d_lam_r) memcpy(d_lam_r, out.data() + R, (size_t)R * 8);
     if (d_pi) memcpy(d_pi, out.data() + 2 * R, 4 * 8);
@@ -2460,7 +2549,7 @@ static int debug_device_lists_run(phylo_ctx* c, int32_t* lists, int64_t n_lists,
         return fail(c, PHYLO_EINVAL, "phylo_debug_device_lists: lists needs %zu ints, meta %d", ints, 6 + 3 * (R + 1));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_ad_off, 0xff, ints * 4, c->stream));        // (what the builders do not write stays -1)
-    CHK(dev_lists_launch(c, c->stream));
+    CHK(dev_lists_launch(c, c->stream, c->stream));
     dl_meta m;
     CHK(dev_lists_wait(c, m));
     HIPCHK(c, hipStreamSynchronize(c->stream));

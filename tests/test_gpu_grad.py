@@ -461,6 +461,30 @@ def test_gradient_same_with_host_built_lists(monkeypatch):
             assert np.max(np.abs(g_dev[key] - g_host[key])) / scale < 1e-12, key
 
 
+def test_adopted_nodes_in_one_launch_equal_a_launch_per_rank_event(monkeypatch):
+    """The adopted nodes' adjoints in ONE launch (workgroups wait for the tiles of their flagged parents: pg_nodes_rows_all) do the
+    arithmetic of the launch per rank event (PHYLO_GRAD_ROWS_CHAIN) in the same order: the same bits, run after run, on a
+    degenerate genealogy (few adopted nodes, long lists) and on a flat one (hundreds of adopted nodes per rank event, chains of
+    flagged parents through every rank event), rows of three tiles.  The chunk sums in quad form (PHYLO_GRAD_QUAD_CHUNKS) differ
+    in the order inside the 4-term products only."""
+    rng = np.random.default_rng(47)
+    N, S, K = 8, 520, 256
+    Q, pi, ll, lr = _model(rng, N)
+    for genome in (_codes_genome(rng, N, S), np.ones((N, S, 4))):
+        runs = [_check(genome, Q, pi, ll, lr, K=K, seed=11)[0] for _ in range(3)]
+        monkeypatch.setenv('PHYLO_GRAD_ROWS_CHAIN', '1')
+        chain = _check(genome, Q, pi, ll, lr, K=K, seed=11)[0]
+        monkeypatch.delenv('PHYLO_GRAD_ROWS_CHAIN')
+        monkeypatch.setenv('PHYLO_GRAD_QUAD_CHUNKS', '1')
+        quad = _check(genome, Q, pi, ll, lr, K=K, seed=11)[0]
+        monkeypatch.delenv('PHYLO_GRAD_QUAD_CHUNKS')
+        for key in ('d_lam_l', 'd_lam_r', 'd_pi', 'd_Q'):
+            for other in runs[1:] + [chain]:
+                assert np.array_equal(np.asarray(runs[0][key]).view(np.uint64), np.asarray(other[key]).view(np.uint64)), key
+            scale = max(np.max(np.abs(quad[key])), 1e-300)
+            assert np.max(np.abs(runs[0][key] - quad[key])) / scale < 1e-12, key
+
+
 def test_gradient_flat_weights_many_adopted_nodes():
     """All-gap rows: every weight equal, so hundreds of distinct ancestors survive each resampling -- many adopted nodes with few
     parents each (the opposite of the degenerate genealogies of real data)."""
