@@ -239,6 +239,8 @@ __global__ __launch_bounds__(64) void pg_G(pg_args a) {
         }
     }
     if (lane == 0) a.G[t] = a.om[t] - sub;
+    // (the tickets of the coefficient launches behind this one start at zero whatever an earlier, failed pass left in them)
+    if (a.coeff_ticket && blockIdx.x == 0 && lane < a.R) a.coeff_ticket[lane] = 0u;
 }
 
 // ---- g3: root-slot coefficients, one rank event per launch (newest first) ---------------------------------

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -1935,8 +1936,12 @@ static int dev_lists_wait(phylo_ctx* c, dl_meta& m) {
 }
 
 static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q, phylo_stats* perf);
+// reverse passes in flight in this process (several host threads, each with its own context): a launch that waits inside the GPU for
+// another launch of its own pass (pg_nodes_rows_all beside pg_coeff_all) assumes the two share the GPU with nobody who waits likewise
+static std::atomic<int> g_backward_in_flight{0};
 
 int phylo_sweep_backward(phylo_ctx* c, double* d_lam_l, double* d_lam_r, double* d_pi, double* d_Q, phylo_stats* perf) {
+    struct in_flight { in_flight() { ++g_backward_in_flight; } ~in_flight() { --g_backward_in_flight; } } guard;
     const int rc = sweep_backward_impl(c, d_lam_l, d_lam_r, d_pi, d_Q, perf);
     if (rc != PHYLO_OK && c) {
         // an early return may have left kernels on the side streams that still read the pinned list image and the graph: join them
@@ -2186,7 +2191,7 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         g.row_timeout = (unsigned int*)(c->hd_dlmeta + PG_DL_META_INTS(R));
         // few enough workgroups to leave the coefficient chain room on every SIMD: the launch runs BESIDE that chain and waits, rank
         // event by rank event, for its completion words; else it is launched behind the chain's last event
-        rows_overlap = (size_t)pinfo.n_slow * (size_t)g.TS <= 512 && !c->env.grad_rows_no_overlap;
+        rows_overlap = (size_t)pinfo.n_slow * (size_t)g.TS <= 512 && !c->env.grad_rows_no_overlap && g_backward_in_flight.load() <= 1;
         g.coeff_done = c->d_row_done + (size_t)R * K * (size_t)cdiv(c->S, 256);
         g.coeff_ticket = g.coeff_done + R;
         g.coeff_mask = 0ull;
