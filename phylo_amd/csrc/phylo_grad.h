@@ -253,12 +253,12 @@ __global__ __launch_bounds__(64) void pg_G(pg_args a) {
 __device__ __forceinline__ double pg_ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void pg_st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // bx, by: the workgroup's place in rank event r's grid (adopted particle, group of four slots); total: that grid's workgroups.
-// wait_word != NULL (pg_coeff_all): rank event r + 1's coefficients are complete when *wait_word == a.row_epoch.  Everything that
+// wait_word != NULL (pg_coeff_all): rank event r + 1's coefficients are complete when *wait_word == wait_for.  Everything that
 // does not depend on them -- the adopters' indices and positions of up to PG_COEFF_PRE x 256 adopters, two dependent loads each --
 // is loaded BEFORE the wait; behind it there is one round of coefficient loads, the sum, the store and the completion word.
 #define PG_COEFF_PRE 4
 __device__ __forceinline__ void pg_coeff_body(const pg_args& a, int r, int adp0, int bx, int by, unsigned int total,
-                                              const unsigned int* wait_word) {
+                                              const unsigned int* wait_word, unsigned int wait_for) {
     const int k = a.adp ? a.adp[adp0 + bx] - r * a.K : bx, lane = threadIdx.x & 63;
     const int slot = by * 4 + (threadIdx.x >> 6);
     const int n1 = a.N - r - 1;
@@ -299,7 +299,7 @@ __device__ __forceinline__ void pg_coeff_body(const pg_args& a, int r, int adp0,
     if (wait_word) {                                         // (uniform)
         if (threadIdx.x == 0) {
             unsigned int spins = 0;
-            while (__hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.row_epoch) {
+            while (__hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait_for) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 18)) {
                     __hip_atomic_store(a.row_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -368,15 +368,14 @@ __device__ __forceinline__ void pg_coeff_body(const pg_args& a, int r, int adp0,
         __syncthreads();
         if (threadIdx.x == 0) {
             const unsigned int t = __hip_atomic_fetch_add(a.coeff_ticket + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == total - 1) {
-                __hip_atomic_store(a.coeff_ticket + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.coeff_done + r, a.row_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            // (pg_coeff_all's workgroups wait for the ticket itself to reach the rank event's count -- one hop less than the word, which
+            //  is for pg_nodes_rows_all; pg_G zeroes the tickets at the head of every pass)
+            if (t == total - 1) __hip_atomic_store(a.coeff_done + r, a.row_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 __global__ __launch_bounds__(256) void pg_coeff(pg_args a, int r, int adp0) {
-    pg_coeff_body(a, r, adp0, (int)blockIdx.x, (int)blockIdx.y, gridDim.x * gridDim.y, nullptr);
+    pg_coeff_body(a, r, adp0, (int)blockIdx.x, (int)blockIdx.y, gridDim.x * gridDim.y, nullptr, 0u);
 }
 // The whole coefficient chain as ONE launch: the grids of all rank events one after the other, newest rank event first (a workgroup
 // is dispatched after everything it waits for); a workgroup of rank event r waits for the completion word of rank event r + 1
@@ -391,7 +390,8 @@ __global__ __launch_bounds__(256) void pg_coeff_all(pg_args a, pg_coeff_plan pl)
     const int bx = local / ny, by = local - bx * ny;
     const int total = r > 0 ? pl.first[r - 1] - pl.first[r] : (int)gridDim.x - pl.first[r];
     const bool waits = r + 1 < a.R - 1 && ((a.coeff_mask >> (r + 1)) & 1ull);   // rank event r + 1 has coefficients of its own
-    pg_coeff_body(a, r, pl.adp0[r], bx, by, (unsigned int)total, waits ? a.coeff_done + r + 1 : nullptr);
+    const unsigned int newer = waits ? (unsigned int)(pl.first[r] - pl.first[r + 1]) : 0u;   // that rank event's workgroups
+    pg_coeff_body(a, r, pl.adp0[r], bx, by, (unsigned int)total, waits ? a.coeff_ticket + r + 1 : nullptr, newer);
 }
 
 // ---- g4: per-leaf sums for d/d pi of the leaf terms -----------------------------------------------------
