@@ -30,7 +30,7 @@ def one(pattern):
     return f[-1] if f else None          # gpurun merges runs into the same directory: take the newest
 
 
-RUNS = [("default", "`python bench.py --steps 40 --warmup 4` (10 sweeps per launch set x 3 contexts in flight: the timed region of the bench line)"),
+RUNS = [("default", "`python bench.py --steps 40 --warmup 4` (launch sets of 20 sweeps on the contexts in flight: the form of the timed region of the bench line)"),
         ("1ctx", "`--streams 1`: the same launch sets one at a time (the form whose merge launches bench.py prices)"),
         ("1stream", "`--streams 1 --batch 1`: one sweep at a time, launches per rank event"),
         ("onelaunch", "`--streams 1 --batch 1 --one-launch`: single sweeps (t_sweep section) in the one-launch form, phylo_persist.h"),
