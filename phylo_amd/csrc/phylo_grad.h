@@ -130,6 +130,8 @@ __device__ __forceinline__ const double* pg_row(const pg_args& a, int id) {
     return id < a.N ? a.leaves + (size_t)id * a.S * 4 : a.pool + (size_t)(id - a.N) * a.S * 4;
 }
 
+__device__ __constant__ double pg_inv_k[19] = {0.0, 1.0 / 1, 1.0 / 2, 1.0 / 3, 1.0 / 4, 1.0 / 5, 1.0 / 6, 1.0 / 7, 1.0 / 8, 1.0 / 9, 1.0 / 10,
+                                                  1.0 / 11, 1.0 / 12, 1.0 / 13, 1.0 / 14, 1.0 / 15, 1.0 / 16, 1.0 / 17, 1.0 / 18};
 // Frechet derivative of the matrix exponential, L(A, E) = d/dt exp(A + t E) at t = 0, by a scaled Taylor
 // series on the pair (X, dX) (the blocks of exp [[A, E], [0, A]]) and pairwise squaring.  ||A||_1 <= 1/2 after
 // scaling and up to 18 terms (chosen from the scaled norm) leave a truncation error below 1e-17.
@@ -161,7 +163,7 @@ __device__ inline void pg_expm4_frechet(const double* A0, const double* E0, doub
     const int nterms = theta <= 0.01 ? 8 : theta <= 0.05 ? 10 : theta <= 0.15 ? 13 : theta <= 0.3 ? 15 : 18;
 #pragma unroll 1
     for (int k = 1; k <= nterms; ++k) {
-        const double inv = 1.0 / (double)k;
+        const double inv = pg_inv_k[k];          // 1 / k, correctly rounded (a division is ~30 dependent instructions per term)
         pm_mm4(X, E, T1);                      // D_k = (X_{k-1} E + D_{k-1} A) / k
         pm_mm4(D, A, T2);
 #pragma unroll
@@ -186,6 +188,85 @@ __device__ inline void pg_expm4_frechet(const double* A0, const double* E0, doub
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) Lout[i] = SD[i];
+}
+
+// The same series with a matrix spread over the four lanes of a quad, lane i holding row i of X, D and of the sums: row i of a
+// product is (row i) x (the right factor), and the right factors of the series are A and E, which every lane holds whole -- the
+// loop needs no exchange and is a quarter as long; only the squarings fetch the other rows (quad broadcasts).  Element by element
+// the arithmetic of pg_expm4_frechet (the same fused chains in the same order).  All four lanes of a quad must be active.
+__device__ __forceinline__ void pg_rowmat(const double (&x)[4], const double* B, double (&y)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double acc = x[0] * B[j];
+        acc = pm_fma(x[1], B[4 + j], acc);
+        acc = pm_fma(x[2], B[8 + j], acc);
+        y[j] = pm_fma(x[3], B[12 + j], acc);
+    }
+}
+template <int I> __device__ __forceinline__ double pg_quad(double v);
+__device__ __forceinline__ void pg_quad_gather(const double (&rowv)[4], double* full) {      // the whole matrix from the quad's four rows
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        full[0 * 4 + j] = pg_quad<0>(rowv[j]);
+        full[1 * 4 + j] = pg_quad<1>(rowv[j]);
+        full[2 * 4 + j] = pg_quad<2>(rowv[j]);
+        full[3 * 4 + j] = pg_quad<3>(rowv[j]);
+    }
+}
+__device__ inline void pg_expm4_frechet_row(const double* A0, const double* E0, int myrow, double (&Lrow)[4]) {
+    double A[16], E[16];
+    double norm = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double cs = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs = cs + (A0[i * 4 + j] < 0.0 ? -A0[i * 4 + j] : A0[i * 4 + j]);
+        if (cs > norm) norm = cs;
+    }
+    int s = 0;
+    double lim = 0.5;
+    while (norm > lim && s < 60) { lim = lim * 2.0; ++s; }
+    const double sc = pm_from_bits((uint64_t)(1023 - s) << 52);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { A[i] = A0[i] * sc; E[i] = E0[i] * sc; }
+    double X[4], D[4], SX[4], SD[4], T1[4], T2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double id = j == myrow ? 1.0 : 0.0;
+        X[j] = id; D[j] = 0.0; SX[j] = id; SD[j] = 0.0;
+    }
+    const double theta = norm * sc;
+    const int nterms = theta <= 0.01 ? 8 : theta <= 0.05 ? 10 : theta <= 0.15 ? 13 : theta <= 0.3 ? 15 : 18;
+#pragma unroll 1
+    for (int k = 1; k <= nterms; ++k) {
+        const double inv = pg_inv_k[k];          // 1 / k, correctly rounded (a division is ~30 dependent instructions per term)
+        pg_rowmat(X, E, T1);                   // D_k = (X_{k-1} E + D_{k-1} A) / k
+        pg_rowmat(D, A, T2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) D[j] = (T1[j] + T2[j]) * inv;
+        pg_rowmat(X, A, T1);                   // X_k = X_{k-1} A / k
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            X[j] = T1[j] * inv;
+            SX[j] = SX[j] + X[j];
+            SD[j] = SD[j] + D[j];
+        }
+    }
+#pragma unroll 1
+    for (int q = 0; q < s; ++q) {              // (R, dR) <- (R R, R dR + dR R); the quad's lanes share s
+        double FX[16], FD[16];
+        pg_quad_gather(SX, FX);
+        pg_quad_gather(SD, FD);
+        pg_rowmat(SX, FD, T1);
+        pg_rowmat(SD, FX, T2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) SD[j] = T1[j] + T2[j];
+        pg_rowmat(SX, FX, T1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) SX[j] = T1[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Lrow[j] = SD[j];
 }
 
 // ---- copies between device memory and PINNED host memory by a kernel (the host pointer is device-visible): the integer lists of
@@ -1148,11 +1229,13 @@ __global__ __launch_bounds__(256, 2) void pg_nodes_rows(pg_args a, int r, int sl
 __global__ __launch_bounds__(256, 2) void pg_nodes_rows_all(pg_args a, int n_slow) { pg_nodes_rows_body<true>(a, 0, n_slow, 0); }
 
 // ---- g6: per node: tiles -> Pl_bar, Pr_bar -> branch adjoints and the Q adjoint ----------------------------
-__global__ __launch_bounds__(64) void pg_node_finish(pg_args a) {
-    // one lane per (node, side): the two Frechet series of a node are ~5 k dependent instructions each and the launch lasts as long
-    // as one lane does (a single lane per node: 36 us); the wave's 32 nodes, grid ceil(R K / 32)
-    const int side = threadIdx.x & 1;
-    const size_t node0 = (size_t)blockIdx.x * 32 + (threadIdx.x >> 1);
+__global__ __launch_bounds__(256) void pg_node_finish(pg_args a) {
+    // four lanes per (node, side) -- lane i has row i of the Frechet series (pg_expm4_frechet_row: a quarter of one lane's ~5 k
+    // dependent instructions; the launch lasts as long as its longest lane: 21 us with a lane per matrix, 36 us with a lane per
+    // node) -- 32 nodes per workgroup of 256 threads, grid ceil(R K / 32)
+    __shared__ double shw[4][20];
+    const int tid = threadIdx.x, row = tid & 3, side = (tid >> 2) & 1;
+    const size_t node0 = (size_t)blockIdx.x * 32 + (tid >> 3);
     const bool valid = node0 < (size_t)a.R * a.K;
     const size_t node = valid ? node0 : (size_t)a.R * a.K - 1;
     double pb[16], pib[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1168,39 +1251,47 @@ __global__ __launch_bounds__(64) void pg_node_finish(pg_args a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) pib[q] = pib[q] + p[32 + q];
     }
-    double Q[16], QP[16], Pm[16];
+    double Q[16], Pm[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) Q[i] = a.Q[i];
     const double* P = a.Pmat + node * 32 + side * 16;
 #pragma unroll
     for (int i = 0; i < 16; ++i) Pm[i] = P[i];
-    pm_mm4(Q, Pm, QP);                                       // dP/db = Q P
-    double bb = 0.0;
+    {                                                        // dP/db = Q P: this lane's row of it, its share of <Pbar, Q P>, then the quad
+        const double qrow[4] = {Q[row * 4], Q[row * 4 + 1], Q[row * 4 + 2], Q[row * 4 + 3]};
+        double qp[4];
+        pg_rowmat(qrow, Pm, qp);
+        double bb = 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bb = bb + pb[i] * QP[i];
-    if (valid) a.nodeg[node * PG_NODEG + side] = bb;
-    double dQ[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) dQ[i] = 0.0;
+        for (int j = 0; j < 4; ++j) bb = bb + (row == 0 ? pb[j] : row == 1 ? pb[4 + j] : row == 2 ? pb[8 + j] : pb[12 + j]) * qp[j];
+        bb = ((pg_quad<0>(bb) + pg_quad<1>(bb)) + pg_quad<2>(bb)) + pg_quad<3>(bb);
+        if (valid && row == 0) a.nodeg[node * PG_NODEG + side] = bb;
+    }
+    double dQ[4] = {0.0, 0.0, 0.0, 0.0};                     // row `row` of this (node, side)'s share of Q_bar
     if (!a.jc) {                                             // <Pbar, L(Qb, E b)> = <b L((Qb)^T, Pbar), E>
         const double b = (side ? a.br : a.bl)[node];
-        double At[16], Lf[16];
+        double At[16], Lr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) At[i * 4 + j] = Q[j * 4 + i] * b;
-        pg_expm4_frechet(At, pb, Lf);
+        pg_expm4_frechet_row(At, pb, row, Lr);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dQ[i] = b * Lf[i];
+        for (int j = 0; j < 4; ++j) dQ[j] = b * Lr[j];
     }
-    // Q_bar and pi_bar are only ever summed over all nodes: the sum over this wave's 32 nodes (left side + right side first, then a
-    // fixed butterfly) goes to fin_part[workgroup][20], which pg_reduce adds up -- not 20 strided columns of R K nodes (28 us)
+    // Q_bar and pi_bar are only ever summed over all nodes: entry by entry over the wave's 8 nodes (a fixed butterfly; a lane
+    // contributes to the four entries of its row), then the four waves in order, to fin_part[workgroup][20], which pg_reduce adds up
+    // -- not 20 strided columns of R K nodes (28 us)
 #pragma unroll
     for (int i = 0; i < 20; ++i) {
-        double v = i < 16 ? dQ[i] : (side == 0 ? pib[i - 16] : 0.0);
+        double v = 0.0;
+        if (i < 16) v = (i >> 2) == row ? dQ[i & 3] : 0.0;
+        else v = (side == 0 && row == 0) ? pib[i - 16] : 0.0;
         v = pg_wave_sum(valid ? v : 0.0);
-        if (threadIdx.x == 0) a.fin_part[(size_t)blockIdx.x * 20 + i] = v;
+        if ((tid & 63) == 0) shw[tid >> 6][i] = v;
     }
+    __syncthreads();
+    if (tid < 20) a.fin_part[(size_t)blockIdx.x * 20 + tid] = ((shw[0][tid] + shw[1][tid]) + shw[2][tid]) + shw[3][tid];
 }
 
 // ---- g7: explicit occurrences of b and lambda in ll_r and in the proposal term; pathwise db/dlambda ---------

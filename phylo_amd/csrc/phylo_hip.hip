@@ -2417,7 +2417,7 @@ static int sweep_backward_impl(phylo_ctx* c, double* d_lam_l, double* d_lam_r, d
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_gjoin, 0));
     }
     if (bg_free) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_bgdone, 0));
-    hipLaunchKernelGGL(pg_node_finish, dim3(cdiv((long)R * K, 32)), dim3(64), 0, c->stream, g);
+    hipLaunchKernelGGL(pg_node_finish, dim3(cdiv((long)R * K, 32)), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_node_finish"));
     hipLaunchKernelGGL(pg_scalars, dim3(nrk), dim3(256), 0, c->stream, g);
     CHK(launch_check(c, "pg_scalars"));
